@@ -1,0 +1,239 @@
+"""HIP kernels vs plain PyTorch fp32 on the same bf16-rounded inputs (per-operator parity, -m gpu).
+
+Tolerances (stated): bf16 outputs rel-L2 <= 3e-3 (one bf16 rounding of the result is ~1e-3 RMS);
+fp32 outputs rel-L2 <= 2e-4 (bf16 x bf16 products are exact in fp32; only summation order differs).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL_BF16, TOL_F32 = 3e-3, 2e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from unirestore_amd import ops as o
+    return o
+
+
+def _rb(t):  # round to bf16 and back
+    return t.to(torch.bfloat16).float()
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def _nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,stride,pad", [
+    (2, 64, 128, 16, 16, 3, 1, 1), (1, 320, 320, 32, 32, 3, 1, 1), (2, 40, 72, 9, 13, 3, 1, 1),
+    (2, 64, 64, 16, 16, 3, 2, 1), (1, 128, 256, 24, 8, 1, 1, 0), (2, 8, 320, 16, 16, 3, 1, 1),
+    (1, 128, 4, 32, 32, 3, 1, 1), (2, 1280, 1280, 8, 8, 3, 1, 1), (8, 640, 320, 8, 8, 1, 1, 0),
+])
+def test_conv_basic(ops, n, cin, cout, h, w, k, stride, pad):
+    g = _gen(cin * 7 + cout)
+    x = _rb(torch.randn(n, cin, h, w, generator=g))
+    wt = _rb(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, stride=stride, padding=pad)
+    pc = ops.pack_conv(wt, b, "cuda")
+    y = ops.conv(_nhwc(x), pc, stride=stride, pad=(pad, pad))
+    assert rel_l2(_nchw(y)[:, :cout], ref) < TOL_BF16
+    y32 = ops.conv(_nhwc(x), pc, stride=stride, pad=(pad, pad), out_f32=True)
+    assert rel_l2(_nchw(y32)[:, :cout], ref) < TOL_F32
+
+
+def test_conv_asym_pad_stride2(ops):
+    """VAE-encoder Downsample2D: F.pad(x,(0,1,0,1)) then 3x3 stride 2, padding 0."""
+    g = _gen(3)
+    x = _rb(torch.randn(2, 64, 16, 16, generator=g)); wt = _rb(torch.randn(64, 64, 3, 3, generator=g) / 24); b = torch.randn(64, generator=g)
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), wt, b, stride=2)
+    y = ops.conv(_nhwc(x), ops.pack_conv(wt, b, "cuda"), stride=2, pad=(0, 0), out_hw=(8, 8))
+    assert rel_l2(_nchw(y), ref) < TOL_BF16
+
+
+def test_conv_concat_upsample_residual_act(ops):
+    g = _gen(4)
+    xa = _rb(torch.randn(2, 64, 8, 8, generator=g)); xb = _rb(torch.randn(2, 32, 8, 8, generator=g))
+    wt = _rb(torch.randn(96, 96, 3, 3, generator=g) / 30); b = torch.randn(96, generator=g)
+    res = _rb(torch.randn(2, 96, 8, 8, generator=g))
+    pc = ops.pack_conv(wt, b, "cuda")
+    ref = F.conv2d(torch.cat([xa, xb], 1), wt, b, padding=1) + res
+    y = ops.conv(_nhwc(xa), pc, x2=_nhwc(xb), residual=_nhwc(res))
+    assert rel_l2(_nchw(y), ref) < TOL_BF16
+    x96 = torch.cat([xa, xb], 1)
+    ref = F.conv2d(F.interpolate(x96, scale_factor=2.0, mode="nearest"), wt, b, padding=1)
+    y = ops.conv(_nhwc(x96), pc, upsample=True)
+    assert rel_l2(_nchw(y), ref) < TOL_BF16
+    for act, fn in ((ops.UR_ACT_SILU, F.silu), (ops.UR_ACT_GELU, F.gelu)):
+        y = ops.conv(_nhwc(x96), pc, act=act)
+        assert rel_l2(_nchw(y), fn(F.conv2d(x96, wt, b, padding=1))) < TOL_BF16
+
+
+def test_linear_geglu_gate_splitk(ops):
+    g = _gen(5)
+    x = _rb(torch.randn(2, 96, 128, generator=g))
+    wt = _rb(torch.randn(1024, 128, generator=g) / 11); b = torch.randn(1024, generator=g)
+    a, gt = F.linear(x, wt, b).chunk(2, -1)
+    y = ops.linear(x.to(torch.bfloat16).cuda(), ops.pack_conv(wt, b, "cuda", pair=True), act=ops.UR_ACT_GEGLU)
+    assert y.shape[-1] == 512 and rel_l2(y.float().cpu(), a * F.gelu(gt)) < TOL_BF16
+    y = ops.linear(x.to(torch.bfloat16).cuda(), ops.pack_conv(wt, b, "cuda", pair=True), act=ops.UR_ACT_GATE)
+    assert rel_l2(y.float().cpu(), a * gt) < TOL_BF16
+    # small M, long K -> split-K path (with residual + pair act through the reduce kernel)
+    x = _rb(torch.randn(64, 2048, generator=g)); wt = _rb(torch.randn(256, 2048, generator=g) / 45); b = torch.randn(256, generator=g)
+    r = _rb(torch.randn(64, 256, generator=g))
+    y = ops.linear(x.to(torch.bfloat16).cuda(), ops.pack_conv(wt, b, "cuda"), residual=r.to(torch.bfloat16).cuda())
+    assert rel_l2(y.float().cpu(), F.linear(x, wt, b) + r) < TOL_BF16
+    a, gt = F.linear(x, wt, b).chunk(2, -1)
+    y = ops.linear(x.to(torch.bfloat16).cuda(), ops.pack_conv(wt, b, "cuda", pair=True), act=ops.UR_ACT_GEGLU)
+    assert rel_l2(y.float().cpu(), a * F.gelu(gt)) < TOL_BF16
+
+
+def test_conv_grouped_colsum_transposed(ops):
+    g = _gen(6)
+    x = _rb(torch.randn(2, 128, 8, 8, generator=g)); wt = _rb(torch.randn(128, 8, 3, 3, generator=g) / 8.5); b = torch.randn(128, generator=g)
+    ref = F.gelu(F.conv2d(x, wt, b, padding=1, groups=16))
+    y = ops.conv(_nhwc(x), ops.pack_conv(wt, b, "cuda", groups=16), act=ops.UR_ACT_GELU)
+    assert rel_l2(_nchw(y), ref) < TOL_BF16
+    # column sums (fused global average pool), no spatial output written
+    x = _rb(torch.randn(2, 64, 16, 16, generator=g)); wt = _rb(torch.randn(96, 64, 3, 3, generator=g) / 24); b = torch.randn(96, generator=g)
+    cs = torch.zeros(2, 96, device="cuda")
+    ops.conv(_nhwc(x), ops.pack_conv(wt, b, "cuda"), colsum=cs, colsum_scale=1.0 / 256)
+    assert rel_l2(cs.cpu(), F.conv2d(x, wt, b, padding=1).mean((2, 3))) < 1e-3
+    # transposed second output (V^T for attention)
+    x = _rb(torch.randn(2, 64, 128, generator=g)); wt = _rb(torch.randn(384, 128, generator=g) / 11)
+    vt = torch.zeros(2, 128, 64, dtype=torch.bfloat16, device="cuda")
+    y = ops.linear(x.to(torch.bfloat16).cuda(), ops.pack_conv(wt, None, "cuda"), yt=vt, n_split=256, t_rows=64)
+    ref = F.linear(x, wt)
+    assert rel_l2(y.float().cpu()[..., :256], ref[..., :256]) < TOL_BF16
+    assert rel_l2(vt.float().cpu(), ref[..., 256:].transpose(1, 2)) < TOL_BF16
+
+
+def test_bmm_nt(ops):
+    g = _gen(7)
+    a = _rb(torch.randn(3, 100, 64, generator=g)); b = _rb(torch.randn(3, 72, 64, generator=g))
+    y = ops.bmm_nt(a.to(torch.bfloat16).cuda(), b.to(torch.bfloat16).cuda(), out_f32=True, out_scale=0.125)
+    assert rel_l2(y.cpu(), a @ b.transpose(1, 2) * 0.125) < TOL_F32
+
+
+@pytest.mark.parametrize("n,c,h,w,groups,silu", [(2, 320, 16, 16, 32, True), (1, 128, 32, 24, 32, False), (2, 64, 7, 9, 16, True),
+                                                 (2, 2560, 4, 4, 32, True), (2, 64, 8, 8, 64, False)])
+def test_groupnorm(ops, n, c, h, w, groups, silu):
+    g = _gen(c)
+    x = _rb(torch.randn(n, c, h, w, generator=g) * 2 + 0.5)
+    inst = groups == c
+    ga, be = (None, None) if inst else (torch.randn(c, generator=g), torch.randn(c, generator=g))
+    ref = F.instance_norm(x, eps=1e-5) if inst else F.group_norm(x, groups, ga, be, eps=1e-5)
+    ref = F.silu(ref) if silu else ref
+    y = ops.group_norm(_nhwc(x), None if inst else ga.cuda(), None if inst else be.cuda(), groups, 1e-5, silu)
+    assert rel_l2(_nchw(y), ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("rows,c", [(300, 320), (64, 1280), (1000, 64), (17, 640)])
+def test_layernorm(ops, rows, c):
+    g = _gen(rows)
+    x = _rb(torch.randn(rows, c, generator=g) * 3 + 1); ga = torch.randn(c, generator=g); be = torch.randn(c, generator=g)
+    y = ops.layer_norm(x.to(torch.bfloat16).cuda(), ga.cuda(), be.cuda(), 1e-5)
+    assert rel_l2(y.float().cpu(), F.layer_norm(x, (c,), ga, be, 1e-5)) < TOL_BF16
+
+
+def test_softmax_rows(ops):
+    s = torch.randn(37, 333, generator=_gen(1)) * 4
+    p = ops.softmax_rows(s.cuda())
+    assert p.shape[-1] == 336 and float(p[:, 333:].abs().sum()) == 0
+    assert rel_l2(p.float().cpu()[:, :333], torch.softmax(s, -1)) < TOL_BF16
+
+
+@pytest.mark.parametrize("b,heads,d,tq,tk", [(2, 2, 64, 256, 256), (1, 5, 64, 1024, 77), (2, 4, 128, 64, 64), (1, 1, 64, 100, 200),
+                                              (2, 4, 128, 256, 77)])
+def test_attention(ops, b, heads, d, tq, tk):
+    g = _gen(tq + tk + d)
+    c = heads * d
+    q = _rb(torch.randn(b, tq, c, generator=g)); k = _rb(torch.randn(b, tk, c, generator=g)); v = _rb(torch.randn(b, tk, c, generator=g))
+    qh, kh, vh = (t.view(b, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(d), -1) @ vh).transpose(1, 2).reshape(b, tq, c)
+    ldvt = (tk + 7) // 8 * 8
+    vt = torch.zeros(b, c, ldvt, dtype=torch.bfloat16); vt[:, :, :tk] = v.transpose(1, 2).to(torch.bfloat16)
+    o = ops.attention(q.to(torch.bfloat16).cuda(), k.to(torch.bfloat16).cuda(), vt.cuda(), heads, d, tq, tk, 1 / math.sqrt(d),
+                      ldq=c, ldk=c, bs_q=tq * c, bs_k=tk * c, bs_vt=c * ldvt, batch=b)
+    assert rel_l2(o.float().cpu(), ref) < 6e-3   # P is rounded to bf16 before PV (as SDPA's bf16 path does)
+
+
+def test_attention_softmax_spike(ops):
+    """Force a large running-max jump mid-stream (online-softmax rescale path)."""
+    g = _gen(9)
+    b, heads, d, t = 1, 1, 64, 256
+    q = _rb(torch.randn(b, t, d, generator=g)); k = _rb(torch.randn(b, t, d, generator=g)); v = _rb(torch.randn(b, t, d, generator=g))
+    k[0, 200] = q[0, 5] * 8
+    ref = torch.softmax(q @ k.transpose(-1, -2) / 8, -1) @ v
+    vt = v.transpose(1, 2).contiguous().to(torch.bfloat16)
+    o = ops.attention(q.to(torch.bfloat16).cuda(), k.to(torch.bfloat16).cuda(), vt.cuda(), 1, d, t, t, 0.125, ldq=d, ldk=d,
+                      bs_q=t * d, bs_k=t * d, bs_vt=d * t, batch=1)
+    assert rel_l2(o.float().cpu(), ref) < 6e-3
+
+
+def test_dwconv_pool_scale_misc(ops):
+    g = _gen(10)
+    x = _rb(torch.randn(2, 64, 9, 11, generator=g)); wt = torch.randn(64, 1, 3, 3, generator=g); b = torch.randn(64, generator=g)
+    w9c = wt.view(64, 9).t().contiguous().cuda()
+    ref = F.conv2d(x, wt, b, padding=1, groups=64)
+    assert rel_l2(_nchw(ops.dwconv3x3(_nhwc(x), w9c, b.cuda())), ref) < TOL_BF16
+    a, c = ref.chunk(2, 1)
+    assert rel_l2(_nchw(ops.dwconv3x3(_nhwc(x), w9c, b.cuda(), gate=True)), a * c) < TOL_BF16
+    assert rel_l2(ops.avgpool(_nhwc(x)).cpu(), x.mean((2, 3))) < 1e-5
+    s = torch.randn(2, 64, generator=g); r = _rb(torch.randn(2, 64, 9, 11, generator=g))
+    y = ops.scale_channels(_nhwc(x), s.cuda(), _nhwc(r))
+    assert rel_l2(_nchw(y), x * s[:, :, None, None] + r) < TOL_BF16
+    sc = torch.randn(64, generator=g)
+    y = ops.axpy_channels(_nhwc(x), _nhwc(r), sc.cuda())
+    assert rel_l2(_nchw(y), x + r * sc[None, :, None, None]) < TOL_BF16
+    xm = torch.randn(5, 96, generator=g); w = torch.randn(40, 96, generator=g); bb = torch.randn(40, generator=g)
+    assert rel_l2(ops.linear_f32(xm.cuda(), w.cuda(), bb.cuda(), ops.UR_ACT_SILU).cpu(), F.silu(F.linear(xm, w, bb))) < 1e-5
+    wg = torch.randn(96, 24, generator=g)
+    refg = torch.cat([F.linear(xm[:, i * 24:(i + 1) * 24], wg[i * 24:(i + 1) * 24]) for i in range(4)], 1)
+    assert rel_l2(ops.linear_f32(xm.cuda(), wg.cuda(), None, groups=4).cpu(), refg) < 1e-5
+    pooled = torch.randn(2, 3, 2 * 48, generator=g); cond = torch.randn(2, 2, 48, generator=g)
+    f, i, cc = (pooled[:, j].view(2, 2, 48) for j in range(3))
+    ref = torch.softmax(f, -1) * cond + torch.softmax(i, -1) * torch.tanh(cc)
+    assert rel_l2(ops.tfa_prompt_update(pooled.cuda(), cond.cuda()).cpu(), ref) < 1e-5
+
+
+def test_boundary_kernels(ops):
+    g = _gen(11)
+    img = torch.rand(2, 3, 16, 24, generator=g)
+    y = ops.nchw_to_nhwc(img.cuda(), image=True)
+    assert y.shape == (2, 16, 24, 8) and float(y[..., 3:].abs().sum()) == 0
+    assert rel_l2(_nchw(y)[:, :3], img * 2 - 1) < TOL_BF16
+    back = ops.nhwc_to_nchw(y, c=3, mul=0.5, add=0.5)
+    assert rel_l2(back.cpu(), img) < 4e-3
+    mom = torch.randn(2, 8, 8, 8, generator=g); noise = torch.randn(2, 4, 8, 8, generator=g)
+    z, zb = ops.vae_sample(mom.cuda(), noise.cuda(), 4, 0.18215)
+    mean, lv = mom.permute(0, 3, 1, 2).chunk(2, 1)
+    ref = (mean + torch.exp(0.5 * lv.clamp(-30, 20)) * noise) * 0.18215
+    assert rel_l2(z.cpu().permute(0, 3, 1, 2)[:, :4], ref) < 1e-6 and float(z[..., 4:].abs().sum()) == 0
+    zt, ztb = ops.add_noise(z, noise.cuda(), 4, 0.3, 0.9)
+    assert rel_l2(zt.cpu().permute(0, 3, 1, 2)[:, :4], 0.3 * ref + 0.9 * noise) < 1e-6
+    eps = torch.randn(2, 8, 8, 4, generator=g).cuda()
+    before = zt.clone()
+    ops.ddim_step_(zt, ztb, eps, 4, 1.7, -0.4)
+    assert rel_l2(zt[..., :4].cpu(), (1.7 * before[..., :4] - 0.4 * eps).cpu()) < 1e-6
+    assert rel_l2(ztb.float().cpu(), zt.cpu()) < TOL_BF16
+
+
+def test_error_convention(ops):
+    x = torch.zeros(1, 4, 4, 12, dtype=torch.bfloat16, device="cuda")
+    pc = ops.pack_conv(torch.zeros(8, 16, 3, 3), None, "cuda")
+    with pytest.raises((ValueError, AssertionError)):
+        ops.conv(x, pc)

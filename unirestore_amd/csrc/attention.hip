@@ -1,0 +1,227 @@
+// Flash-style attention forward for gfx950 (bf16 MFMA 32x32x16, fp32 online softmax).
+//
+// Layout choices (CDNA4-first):
+//   * S^T = K.Q^T ("swapped" product): the accumulator lane owns ONE query column (q = lane&31), so the row
+//     max / row sum are 32 in-register ops + one cross-half exchange, and the O rescale is a per-lane scalar.
+//   * O^T = V^T.P^T with V stored TRANSPOSED in memory ([channel][key], written that way by the producing
+//     GEMM's epilogue): both MFMA operands are then K-contiguous 16-byte LDS reads - no transpose anywhere.
+//   * K rows are read from LDS through a bit-2/3 swap of the row index so that the S^T accumulator registers,
+//     packed pairwise to bf16, ARE the P^T B-operand (8 consecutive keys per lane) - no shuffles for P.
+//   * 4 waves x 32 queries per workgroup share 64-key K / V^T tiles staged through registers into
+//     XOR-swizzled LDS (2 stages, one barrier per tile); swizzles verified by tools/lds_conflicts.py.
+#include "common.h"
+
+namespace {
+
+struct AttnP {
+  const uint16_t* q; const uint16_t* k; const uint16_t* vt; uint16_t* o;
+  int B, H, Tq, Tk, ldq, ldk, ldvt, ldo;
+  long long bs_q, bs_k, bs_vt, bs_o;
+  float scale_log2e;
+};
+
+__device__ __forceinline__ int swap23(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+  constexpr int KROW = D * 2;                 // bytes per K row in LDS
+  constexpr int KSLOTS = KROW / 16;           // 16-B slots per K row (8 or 16)
+  constexpr int KT = 64 * KROW;               // K tile bytes
+  constexpr int VT = D * 128;                 // V^T tile bytes: D rows x 64 keys
+  constexpr int STAGE = KT + VT;
+  constexpr int DS = D / 16;                  // QK^T k-steps
+  constexpr int DF = D / 32;                  // O^T row fragments
+  constexpr int KLD = KT / 4096;              // uint4 loads per thread for K tile (2 or 4)
+  constexpr int VLD = VT / 4096;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+
+  const uint16_t* Q = p.q + b * p.bs_q + h * D;
+  const uint16_t* K = p.k + b * p.bs_k + h * D;
+  const uint16_t* V = p.vt + b * p.bs_vt + (long long)h * D * p.ldvt;
+
+  // Q fragments (B operand): lane -> query q0 + l31, dims ds*16 + hf*8 .. +7
+  bf16x8 qf[DS];
+  {
+    const int qi = min(q0 + l31, p.Tq - 1);
+    const uint16_t* qp = Q + (long long)qi * p.ldq + hf * 8;
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
+  }
+
+  uint4 kr[KLD], vr[VLD];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+      const int idx = i * 256 + tid, row = idx / KSLOTS, slot = idx % KSLOTS;
+      const bool ok = kv0 + row < p.Tk;
+      const uint4* ptr = reinterpret_cast<const uint4*>(ok ? K + (long long)(kv0 + row) * p.ldk + slot * 8 : K);
+      uint4 v = *ptr;
+      kr[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int idx = i * 256 + tid, row = idx >> 3, slot = idx & 7;
+      const bool ok = kv0 + slot * 8 < p.ldvt;   // padding columns [Tk, ldvt) are zero by contract
+      const uint4* ptr = reinterpret_cast<const uint4*>(ok ? V + (long long)row * p.ldvt + kv0 + slot * 8 : V);
+      uint4 v = *ptr;
+      vr[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int stage) {
+    unsigned char* ks = smem + stage * STAGE;
+    unsigned char* vs = ks + KT;
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+      const int idx = i * 256 + tid, row = idx / KSLOTS, slot = idx % KSLOTS;
+      const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+      *reinterpret_cast<uint4*>(ks + row * KROW + ((slot ^ sw) << 4)) = kr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int idx = i * 256 + tid, row = idx >> 3, slot = idx & 7;
+      *reinterpret_cast<uint4*>(vs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = vr[i];
+    }
+  };
+
+  f32x16 oacc[DF];
+#pragma unroll
+  for (int f = 0; f < DF; ++f)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[f][e] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int ntiles = (p.Tk + 63) / 64;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  int stage = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) load_tile((t + 1) * 64);
+    const unsigned char* ks = smem + stage * STAGE;
+    const unsigned char* vs = ks + KT;
+
+    // ---- S^T = K Q^T : two 32-key fragments -----------------------------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[f][e] = 0.f;
+      const int row = f * 32 + swap23(l31);
+      const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + row * KROW + (((ds * 2 + hf) ^ sw) << 4));
+        sacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc[f], 0, 0, 0);
+      }
+    }
+    // register r of fragment f, half hf  <->  key  t*64 + f*32 + 16*(r>>3) + 8*hf + (r&7)
+    float s[32];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[f * 16 + r] = sacc[f][r] * p.scale_log2e;
+    if ((t + 1) * 64 > p.Tk) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + f * 32 + 16 * (r >> 3) + 8 * hf + (r & 7);
+          if (key >= p.Tk) s[f * 16 + r] = -INFINITY;
+        }
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) mx = fmaxf(mx, s[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      s[i] = __builtin_amdgcn_exp2f(s[i] - m_new);
+      psum += s[i];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int f = 0; f < DF; ++f)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[f][e] *= alpha;
+
+    // ---- O^T += V^T P^T : 4 k-steps of 16 keys; P^T fragment = 8 consecutive accumulator registers ----
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      uint4 pk;
+      const float* sp = s + kk * 8;
+      pk.x = pack2bf(sp[0], sp[1]); pk.y = pack2bf(sp[2], sp[3]);
+      pk.z = pack2bf(sp[4], sp[5]); pk.w = pack2bf(sp[6], sp[7]);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+      for (int f = 0; f < DF; ++f) {
+        const int row = f * 32 + l31;
+        bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs + row * 128 + (((kk * 2 + hf) ^ ((row >> 1) & 7)) << 4));
+        oacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[f], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(stage ^ 1);
+    __syncthreads();
+    stage ^= 1;
+  }
+
+  // ---- normalise and store: lane owns query q0+l31, channels f*32 + 8*g + 4*hf + e ------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  const int qi = q0 + l31;
+  if (qi < p.Tq) {
+    uint16_t* op = p.o + b * p.bs_o + (long long)qi * p.ldo + h * D;
+#pragma unroll
+    for (int f = 0; f < DF; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = f * 32 + 8 * g + 4 * hf;
+        *reinterpret_cast<uint2*>(op + c) =
+            make_uint2(pack2bf(oacc[f][g * 4] * inv, oacc[f][g * 4 + 1] * inv),
+                       pack2bf(oacc[f][g * 4 + 2] * inv, oacc[f][g * 4 + 3] * inv));
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk, int D,
+                                int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k, long long bs_vt,
+                                long long bs_o, float scale, ur_stream_t stream) {
+  UR_REQUIRE(q && k && vt && o, "null pointer");
+  UR_REQUIRE(D == 64 || D == 128, "head dim must be 64 or 128 (use the GEMM path otherwise)");
+  UR_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "empty problem");
+  UR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Tk, "leading dims");
+  AttnP p;
+  p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.vt = (const uint16_t*)vt; p.o = (uint16_t*)o;
+  p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
+  p.bs_q = bs_q; p.bs_k = bs_k; p.bs_vt = bs_vt; p.bs_o = bs_o;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 4.0 * B * H * (double)Tq * Tk * D;
+  const double bytes = 2.0 * B * H * ((double)Tq * D * 2 + (double)Tk * D * 2);
+  ur::ProfScope prof("attention", flops, bytes, s);
+  dim3 grid((Tq + 127) / 128, B * H), block(256);
+  if (D == 64) {
+    constexpr int lds = 2 * (64 * 128 + 64 * 128);
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, lds, s, p);
+  } else {
+    constexpr int lds = 2 * (64 * 256 + 128 * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, lds, s, p);
+  }
+  return ur::check_launch("ur_attention_fwd");
+}

@@ -1,0 +1,74 @@
+// Shared device helpers + host-side error / profiling plumbing for libunirestore_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/unirestore_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ------------------------------------------------------------------------------------------ bf16
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+// ------------------------------------------------------------------------------------------ math
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case UR_ACT_SILU: return silu_f(x);
+    case UR_ACT_GELU: return gelu_f(x);
+    case UR_ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ host
+namespace ur {
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int check_launch(const char* what);
+
+// Live timing: one (start, stop) hipEvent pair around each launch, on the launch stream.
+struct ProfScope {
+  ProfScope(const char* family, double flops, double bytes, hipStream_t s);
+  ~ProfScope();
+  int slot;
+  hipStream_t stream;
+};
+}  // namespace ur
+
+#define UR_REQUIRE(cond, msg) \
+  do {                        \
+    if (!(cond)) return ur::fail(UR_E_INVALID, std::string(__func__) + ": " + (msg)); \
+  } while (0)

@@ -1,0 +1,397 @@
+// Implicit-GEMM convolution / linear for gfx950: NHWC bf16 activations, [Cout][KH*KW*Cin] bf16 weights,
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulate, fused epilogues.  See include/unirestore_hip.h.
+//
+// Mapping (MI355X-first, not a cuDNN-style port):
+//   * GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin; the K index runs (tap, cin) so every
+//     16-byte vector a lane loads is 8 contiguous input channels of ONE pixel (NHWC) or of one weight row.
+//   * MFMA "A" operand = weight rows (cout), "B" operand = pixels, so each lane of the 32x32 accumulator
+//     holds 4 CONSECUTIVE output channels of one pixel -> 8-byte bf16 stores straight into NHWC.
+//   * 256 threads = 4 waves; register-staged global->LDS pipeline (issue tile t+1 loads, compute tile t,
+//     write LDS, one barrier per 64-deep K tile), 2 LDS stages.
+//   * LDS tile = [row][128 B] with the 16-B slot XOR-swizzled by (row>>1)&7: conflict-free for both the
+//     ds_write_b128 staging pattern and the ds_read_b128 fragment pattern of 32-row MFMA operands.
+//   * zero padding, stride, nearest-2x upsample and channel concat are address arithmetic in the loader.
+//   * block id -> tile map is XCD-aware (blocks that share an activation tile land on one XCD's L2).
+#include "common.h"
+
+namespace {
+
+struct ConvK {
+  const uint16_t* x; const uint16_t* x2; const uint16_t* w; const float* bias; const uint16_t* res;
+  void* y; uint16_t* yt; float* colsum; float* ws;
+  int N, H, W, C1, ldx, C2, ldx2, Cin, Cout, ldw, ldy, ldr, KH, KW, stride, pad_t, pad_l, OH, OW, OHW;
+  int ups, act, out_f32, n_split, t_rows, t_ld;
+  float out_scale, colsum_scale;
+  int M, Ktot, nk, tiles_m, tiles_n, splitk, nk_per_split, nbatch;
+  long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r;
+  size_t ws_bytes_;
+};
+
+__device__ __forceinline__ bool is_pair_act(int act) { return act == UR_ACT_GEGLU || act == UR_ACT_GATE; }
+
+// Final stage for 4 consecutive output channels [co, co+4) of pixel row m (values already activated/scaled).
+__device__ __forceinline__ void epi_store(const ConvK& p, int gb, int m, int co, float v[4]) {
+  if (p.res) {
+    const uint16_t* r = p.res + gb * p.bs_r + (long long)m * p.ldr + co;
+    uint2 rv = *reinterpret_cast<const uint2*>(r);
+    v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+    v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+  }
+  if (p.yt && co >= p.n_split) {
+    int b = m / p.t_rows, t = m - b * p.t_rows;
+    int cw = p.Cout - p.n_split;
+    uint16_t* o = p.yt + ((long long)b * cw + (co - p.n_split)) * p.t_ld + t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[(long long)e * p.t_ld] = f2bf(v[e]);
+    return;
+  }
+  if (!p.y) return;
+  if (p.out_f32) {
+    float* o = reinterpret_cast<float*>(p.y) + gb * p.bs_y + (long long)m * p.ldy + co;
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    uint16_t* o = reinterpret_cast<uint16_t*>(p.y) + gb * p.bs_y + (long long)m * p.ldy + co;
+    *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+  }
+}
+
+// bias + activation + scale on a quad; `g` is the gate quad for pair activations. co_in = column in the
+// GEMM's N space (pre-pairing); returns the output column.
+__device__ __forceinline__ int epi_act(const ConvK& p, int gb, int co_in, float a[4], const float g[4]) {
+  if (p.bias) {
+    const float* b = p.bias + gb * p.bs_bias + co_in;
+    float4 bv = *reinterpret_cast<const float4*>(b);
+    a[0] += bv.x; a[1] += bv.y; a[2] += bv.z; a[3] += bv.w;
+  }
+  int co = co_in;
+  if (is_pair_act(p.act)) {
+    float gg[4] = {g[0], g[1], g[2], g[3]};
+    if (p.bias) {
+      float4 bv = *reinterpret_cast<const float4*>(p.bias + gb * p.bs_bias + co_in + 32);
+      gg[0] += bv.x; gg[1] += bv.y; gg[2] += bv.z; gg[3] += bv.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] *= (p.act == UR_ACT_GEGLU) ? gelu_f(gg[e]) : gg[e];
+    co = (co_in >> 6) * 32 + (co_in & 31);
+  } else if (p.act != UR_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = apply_act(a[e], p.act);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a[e] *= p.out_scale;
+  return co;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, XP = BM / 32, WP = BN / 32;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(WM * WN == 4 && WTM % 32 == 0 && WTN % 32 == 0, "tile/wave shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid % WM, wn = wid / WM;
+  const int gb = blockIdx.y, sz = blockIdx.z;
+
+  // XCD-aware bijective remap: XCD (id % 8) owns a contiguous run of tiles, n-tile fastest.
+  int id = blockIdx.x;
+  {
+    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
+  const uint16_t* __restrict__ X2 = p.x2 ? p.x2 + gb * p.bs_x2 : nullptr;
+  const uint16_t* __restrict__ Wt = p.w + gb * p.bs_w;
+
+  // ---- loader geometry: thread -> (row = pass*32 + tid/8, 16-B chunk = tid%8) -----------------------
+  const int chunk = tid & 7, lrow = tid >> 3;
+  int ih0[XP], iw0[XP], nb[XP];
+  bool xok[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    int m = m0 + i * 32 + lrow;
+    xok[i] = m < p.M;
+    int mm = xok[i] ? m : 0;
+    int n = mm / p.OHW, rem = mm - n * p.OHW;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    ih0[i] = oh * p.stride - p.pad_t;
+    iw0[i] = ow * p.stride - p.pad_l;
+    nb[i] = n * p.H;
+  }
+  long long woff[WP];
+  bool wok[WP];
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    int row = n0 + j * 32 + lrow;
+    wok[j] = row < p.Cout;
+    woff[j] = (long long)(wok[j] ? row : 0) * p.ldw;
+  }
+  const int Hlim = p.ups ? p.H * 2 : p.H, Wlim = p.ups ? p.W * 2 : p.W;
+
+  const int kt_begin = sz * p.nk_per_split;
+  const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
+  int kcur = kt_begin * 64 + chunk * 8;
+  int tap = kcur / p.Cin, cch = kcur - tap * p.Cin;
+
+  uint4 xr[XP], wr[WP];
+  auto load_tile = [&]() {
+    const bool kval = kcur < p.Ktot;
+    const int dy = (p.KW == 1) ? 0 : (tap * 11) >> 5;
+    const int dx = tap - dy * p.KW;
+    const uint16_t* src = X1;
+    int ld = p.ldx, cc = cch;
+    if (cch >= p.C1) { src = X2; ld = p.ldx2; cc = cch - p.C1; }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      int ih = ih0[i] + dy, iw = iw0[i] + dx;
+      bool v = kval && xok[i] && (unsigned)ih < (unsigned)Hlim && (unsigned)iw < (unsigned)Wlim;
+      if (p.ups) { ih >>= 1; iw >>= 1; }
+      long long off = ((long long)(nb[i] + ih) * p.W + iw) * ld + cc;
+      const uint4* ptr = reinterpret_cast<const uint4*>(v ? src + off : src);
+      uint4 val = *ptr;
+      xr[i] = v ? val : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      bool v = kval && wok[j];
+      const uint4* ptr = reinterpret_cast<const uint4*>(v ? Wt + woff[j] + kcur : Wt);
+      uint4 val = *ptr;
+      wr[j] = v ? val : make_uint4(0, 0, 0, 0);
+    }
+    kcur += 64;
+    cch += 64;
+    while (cch >= p.Cin) { cch -= p.Cin; ++tap; }
+  };
+  auto store_tile = [&](int stage) {
+    unsigned char* xs = smem + stage * STAGE;
+    unsigned char* wsm = xs + BM * 128;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      int row = i * 32 + lrow;
+      *reinterpret_cast<uint4*>(xs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = xr[i];
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      int row = j * 32 + lrow;
+      *reinterpret_cast<uint4*>(wsm + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = wr[j];
+    }
+  };
+
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  auto compute = [&](int stage) {
+    const unsigned char* xs = smem + stage * STAGE;
+    const unsigned char* wsm = xs + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int slot = ks * 2 + fhalf;
+      bf16x8 bfr[FM], afr[FN];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        int row = wm * WTM + b * 32 + frow;
+        bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < FN; ++a) {
+        int row = wn * WTN + a * 32 + frow;
+        afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop ---------------------------------------------------------------------------------------
+  if (kt_begin < kt_end) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    int stage = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool more = kt + 1 < kt_end;
+      if (more) load_tile();
+      compute(stage);
+      if (more) store_tile(stage ^ 1);
+      __syncthreads();
+      stage ^= 1;
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------
+  const int mrow = lane & 31;
+  if (p.splitk > 1) {
+    float* ws = p.ws + ((long long)(sz * p.nbatch + gb) * p.M) * p.Cout;
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        int m = m0 + wm * WTM + b * 32 + mrow;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
+          if (m < p.M && co < p.Cout)
+            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =
+                make_float4(acc[a][b][rg * 4], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
+        }
+      }
+    return;
+  }
+  const bool pair = is_pair_act(p.act);
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    if (pair && (a & 1)) continue;
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      int m = m0 + wm * WTM + b * 32 + mrow;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        int co_in = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
+        bool ok = m < p.M && co_in < p.Cout;
+        float v[4], g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][rg * 4 + e];
+        if (pair) {
+          constexpr int a1 = (FN > 1) ? 1 : 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = acc[(a + a1) % FN][b][rg * 4 + e];
+        }
+        int co = co_in;
+        if (ok) co = epi_act(p, gb, co_in, v, g);
+        if (p.colsum) {  // per-image column sums of the activated output (all 32 lanes share co)
+          int mclamp = min(m, p.M - 1);
+          int img = mclamp / p.OHW;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float s = ok ? v[e] : 0.f;
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+            if (mrow == 0 && co_in < p.Cout) {
+              int cw = pair ? p.Cout / 2 : p.Cout;
+              atomicAdd(p.colsum + ((long long)gb * p.N + img) * cw + co + e, s * p.colsum_scale);
+            }
+          }
+        }
+        if (ok) epi_store(p, gb, m, co, v);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p) {
+  const bool pair = is_pair_act(p.act);
+  const int qn = p.Cout / 4;  // quads per row in GEMM N space
+  long long total = (long long)p.nbatch * p.M * qn;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int q = (int)(i % qn);
+    long long r = i / qn;
+    int m = (int)(r % p.M), gb = (int)(r / p.M);
+    int co_in = q * 4;
+    if (pair && (co_in & 32)) continue;  // gate quads are consumed by their 'a' partner
+    float v[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+    for (int s = 0; s < p.splitk; ++s) {
+      const float* ws = p.ws + ((long long)(s * p.nbatch + gb) * p.M + m) * p.Cout + co_in;
+      float4 t = *reinterpret_cast<const float4*>(ws);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      if (pair) {
+        float4 u = *reinterpret_cast<const float4*>(ws + 32);
+        g[0] += u.x; g[1] += u.y; g[2] += u.z; g[3] += u.w;
+      }
+    }
+    int co = epi_act(p, gb, co_in, v, g);
+    if (p.colsum) {
+      int cw = pair ? p.Cout / 2 : p.Cout;
+      for (int e = 0; e < 4; ++e)
+        atomicAdd(p.colsum + ((long long)gb * p.N + m / p.OHW) * cw + co + e, v[e] * p.colsum_scale);
+    }
+    epi_store(p, gb, m, co, v);
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(ConvK& k, hipStream_t s) {
+  k.tiles_m = (k.M + BM - 1) / BM;
+  k.tiles_n = (k.Cout + BN - 1) / BN;
+  const long long blocks = (long long)k.tiles_m * k.tiles_n * k.nbatch;
+  int splitk = 1;
+  if (blocks < 200 && k.nk >= 8 && k.ws) {
+    long long want = (384 + blocks - 1) / blocks;
+    long long cap_k = k.nk / 4;
+    splitk = (int)std::min<long long>(std::min<long long>(want, cap_k), 16);
+    long long need = (long long)splitk * k.nbatch * k.M * k.Cout * 4;
+    while (splitk > 1 && need > (long long)k.ws_bytes_) { --splitk; need = (long long)splitk * k.nbatch * k.M * k.Cout * 4; }
+    if (splitk < 1) splitk = 1;
+  }
+  k.splitk = splitk;
+  k.nk_per_split = (k.nk + splitk - 1) / splitk;
+  k.splitk = (k.nk + k.nk_per_split - 1) / k.nk_per_split;
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, k);
+  if (k.splitk > 1) {
+    long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
+    int rb = (int)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
+  }
+  return ur::check_launch("ur_conv2d_nhwc");
+}
+
+}  // namespace
+
+extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
+  UR_REQUIRE(d && d->x && d->w, "null x/w");
+  UR_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3), "only 1x1 and 3x3 kernels");
+  UR_REQUIRE(d->C1 > 0 && d->C1 % 8 == 0 && d->C2 % 8 == 0 && d->ldx % 8 == 0, "Cin/ldx must be multiples of 8");
+  UR_REQUIRE(d->C2 == 0 || (d->x2 && d->ldx2 % 8 == 0), "virtual concat needs x2");
+  UR_REQUIRE(d->Cout > 0 && d->Cout % 4 == 0 && d->ldw % 8 == 0, "Cout%4, ldw%8");
+  UR_REQUIRE(d->nbatch >= 1 && d->stride >= 1 && d->OH > 0 && d->OW > 0, "bad dims");
+  UR_REQUIRE(d->y || d->yt || d->colsum, "no output requested");
+  const bool pair = d->act == UR_ACT_GEGLU || d->act == UR_ACT_GATE;
+  UR_REQUIRE(!pair || d->Cout % 64 == 0, "pair activations need Cout%64==0 (32-row a|g interleave)");
+  UR_REQUIRE(!d->y || (d->out_f32 ? d->ldy % 4 == 0 : d->ldy % 4 == 0), "ldy%4");
+  UR_REQUIRE(!d->residual || d->ldr % 4 == 0, "ldr%4");
+  UR_REQUIRE(!d->yt || (d->t_rows > 0 && d->n_split % 4 == 0 && !pair), "bad transposed-output spec");
+  UR_REQUIRE(!d->colsum || ((d->OH * d->OW) % 32 == 0), "colsum needs OH*OW % 32 == 0");
+
+  ConvK k;
+  k.x = (const uint16_t*)d->x; k.x2 = (const uint16_t*)d->x2; k.w = (const uint16_t*)d->w; k.bias = d->bias;
+  k.res = (const uint16_t*)d->residual; k.y = d->y; k.yt = (uint16_t*)d->yt; k.colsum = d->colsum;
+  k.ws = d->workspace; k.ws_bytes_ = d->workspace_bytes;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.C1 = d->C1; k.ldx = d->ldx; k.C2 = d->C2; k.ldx2 = d->ldx2;
+  k.Cin = d->C1 + d->C2; k.Cout = d->Cout; k.ldw = d->ldw; k.ldy = d->ldy; k.ldr = d->ldr;
+  k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l;
+  k.OH = d->OH; k.OW = d->OW; k.OHW = d->OH * d->OW; k.ups = d->upsample2x; k.act = d->act; k.out_f32 = d->out_f32;
+  k.n_split = d->yt ? d->n_split : d->Cout; k.t_rows = d->t_rows; k.t_ld = d->t_ld;
+  k.out_scale = d->out_scale; k.colsum_scale = d->colsum_scale;
+  k.M = d->N * d->OH * d->OW; k.Ktot = d->KH * d->KW * k.Cin; k.nk = (k.Ktot + 63) / 64; k.nbatch = d->nbatch;
+  k.bs_x = d->bs_x; k.bs_x2 = d->bs_x2; k.bs_w = d->bs_w; k.bs_bias = d->bs_bias; k.bs_y = d->bs_y; k.bs_r = d->bs_r;
+  UR_REQUIRE(k.M > 0, "empty problem");
+
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 2.0 * k.M * (double)k.Cout * k.Ktot * k.nbatch;
+  const double bytes = 2.0 * ((double)k.M * k.Cin + (double)k.Cout * k.Ktot + (double)k.M * k.Cout) * k.nbatch;
+  ur::ProfScope prof(d->KH == 3 ? "conv3x3_igemm" : "gemm1x1_igemm", flops, bytes, s);
+  if (pair) return launch_cfg<128, 128, 2, 2>(k, s);  // a|g 32-row blocks must sit in one wave tile
+  if (k.Cout <= 32) return launch_cfg<256, 32, 4, 1>(k, s);
+  if (k.Cout <= 64) return launch_cfg<128, 64, 2, 2>(k, s);
+  if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_cfg<128, 160, 4, 1>(k, s);
+  return launch_cfg<128, 128, 2, 2>(k, s);
+}

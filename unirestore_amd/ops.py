@@ -1,0 +1,310 @@
+"""Torch-tensor front end of the HIP kernels (device pointers + current HIP stream -> C ABI).
+
+Activations are NHWC bf16 tensors ([N,H,W,C] or [rows, C]); C is always a multiple of 8 (thin tensors such as
+images / latents are zero-padded to 8 channels).  PyTorch only owns memory and the stream here.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import capi
+from .capi import UR_ACT_GATE, UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_SILU, UR_ACT_TANH, ConvDesc, check, lib
+
+BF16 = torch.bfloat16
+_ws = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def workspace(dev, nbytes=192 << 20) -> torch.Tensor:
+    key = (dev, "splitk")
+    if key not in _ws or _ws[key].numel() * 4 < nbytes:
+        _ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    return _ws[key]
+
+
+def _gn_ws(dev, nbytes) -> torch.Tensor:
+    key = (dev, "gn")
+    if key not in _ws or _ws[key].numel() * 8 < nbytes:
+        _ws[key] = torch.empty(max(nbytes // 8, 1 << 16), dtype=torch.float64, device=dev)
+    return _ws[key]
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------ weights
+@dataclass
+class PackedConv:
+    """bf16 [Cout][KH*KW*Cin] weight (K runs tap-major, channel-minor) + fp32 bias, padded for the kernel."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    cin: int          # padded input channels (multiple of 8)
+    cout: int         # GEMM N (multiple of 4; for pair activations the interleaved a|g row count)
+    cout_out: int     # channels actually produced (cout/2 for pair activations)
+    k: int            # kernel size (1 or 3)
+    groups: int = 1
+    pair: bool = False
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=False, groups=1, cin_pad=None) -> PackedConv:
+    """weight: [Cout, Cin/groups, k, k] (nn.Conv2d) or [N, K] (nn.Linear), fp32 master on any device."""
+    w = weight.detach().to(torch.float32)
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin_g, kh, kw = w.shape
+    assert kh == kw and kh in (1, 3)
+    cin_p = cin_pad or round_up(cin_g, 8)
+    cout_p = round_up(cout, 4)
+    if groups > 1:
+        assert cin_g % 8 == 0 and (cout // groups) % 4 == 0
+    wp = torch.zeros(cout_p, kh, kw, cin_p, dtype=torch.float32)
+    wp[:cout, :, :, :cin_g] = w.permute(0, 2, 3, 1).cpu()
+    b = None
+    if bias is not None:
+        b = torch.zeros(cout_p, dtype=torch.float32)
+        b[:cout] = bias.detach().float().cpu()
+    cout_out = cout_p
+    if pair:
+        half = cout // 2
+        assert cout % 2 == 0 and half % 32 == 0, "pair activations need (Cout/2) % 32 == 0"
+        idx = torch.arange(cout).view(2, half // 32, 32).permute(1, 0, 2).reshape(-1)   # [blk][a|g][32]
+        wp = wp[idx]
+        b = b[idx] if b is not None else None
+        cout_out = half
+    return PackedConv(wp.reshape(cout_p, kh * kw * cin_p).to(dev, BF16).contiguous(),
+                      None if b is None else b.to(dev).contiguous(), cin_p, cout_p, cout_out, kh, groups, pair)
+
+
+# ------------------------------------------------------------------------------------------------ conv / gemm
+def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, act=UR_ACT_NONE, stride=1, pad=None,
+         out_hw=None, upsample=False, out_f32=False, out_scale=1.0, out=None, yt=None, n_split=0, t_rows=0,
+         colsum=None, colsum_scale=1.0):
+    """x: [N,H,W,C1] bf16 (x2 optional [N,H,W,C2], virtual concat).  Returns [N,OH,OW,cout_out]."""
+    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+    n, h, w_, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    g = pc.groups
+    assert (c1 + c2) == pc.cin * g, f"Cin mismatch: {c1}+{c2} vs {pc.cin}*{g}"
+    k = pc.k
+    if pad is None:
+        pad = (k // 2, k // 2)
+    hin, win = (h * 2, w_ * 2) if upsample else (h, w_)
+    if out_hw is None:
+        out_hw = ((hin + 2 * pad[0] - k) // stride + 1, (win + 2 * pad[1] - k) // stride + 1)
+    oh, ow = out_hw
+    co_total = pc.cout_out
+    if out is None and colsum is None:
+        out = torch.empty((n, oh, ow, co_total), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    d = ConvDesc()
+    d.x, d.x2, d.w, d.bias = _ptr(x), _ptr(x2), _ptr(pc.w), _ptr(pc.bias)
+    d.residual, d.y, d.yt, d.colsum = _ptr(residual), _ptr(out), _ptr(yt), _ptr(colsum)
+    ws = workspace(x.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    d.N, d.H, d.W = n, h, w_
+    d.C1, d.ldx, d.C2, d.ldx2 = (c1 // g if g > 1 else c1), c1, c2, c2
+    d.Cout = pc.cout // g
+    d.ldw = pc.w.shape[1]
+    d.ldy = out.shape[-1] if out is not None else co_total
+    d.ldr = residual.shape[-1] if residual is not None else 0
+    d.KH = d.KW = k
+    d.stride, d.pad_t, d.pad_l, d.OH, d.OW = stride, pad[0], pad[1], oh, ow
+    d.upsample2x, d.act, d.out_f32 = int(upsample), act, int(out_f32)
+    d.n_split, d.t_rows = n_split, t_rows
+    d.t_ld = yt.shape[-1] if yt is not None else 0
+    d.out_scale, d.colsum_scale = out_scale, colsum_scale
+    d.nbatch = g
+    if g > 1:
+        d.bs_x, d.bs_w, d.bs_bias, d.bs_y = c1 // g, (pc.cout // g) * pc.w.shape[1], pc.cout // g, pc.cout_out // g
+        d.bs_r = pc.cout_out // g
+    check(lib.ur_conv2d_nhwc(d, _stream()))
+    return out
+
+
+def linear(x: torch.Tensor, pc: PackedConv, **kw):
+    """x: [..., K] bf16 -> [..., N]; runs as a 1x1 conv over a [1,1,rows,K] image."""
+    shp = x.shape
+    rows = x.numel() // shp[-1]
+    res = kw.pop("residual", None)
+    if res is not None:
+        res = res.reshape(1, 1, rows, res.shape[-1])
+    y = conv(x.reshape(1, 1, rows, shp[-1]), pc, residual=res, **kw)
+    return None if y is None else y.reshape(*shp[:-1], y.shape[-1])
+
+
+def bmm_nt(a: torch.Tensor, bmat: torch.Tensor, *, out_f32=False, out_scale=1.0):
+    """Batched C[b] = A[b] @ B[b]^T with A:[B,M,K], B:[B,N,K] bf16 (last dim contiguous; row strides free)."""
+    B, M, K = a.shape
+    N = bmat.shape[1]
+    assert a.stride(2) == 1 and bmat.stride(2) == 1 and K % 8 == 0 and N % 4 == 0
+    out = torch.empty((B, M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    d = ConvDesc()
+    d.x, d.w, d.y = a.data_ptr(), bmat.data_ptr(), out.data_ptr()
+    ws = workspace(a.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    d.N, d.H, d.W, d.C1, d.ldx, d.Cout, d.ldw, d.ldy = 1, 1, M, K, a.stride(1), N, bmat.stride(1), N
+    d.KH = d.KW = 1
+    d.stride, d.OH, d.OW, d.out_f32, d.out_scale, d.nbatch = 1, 1, M, int(out_f32), out_scale, B
+    d.bs_x, d.bs_w, d.bs_y = a.stride(0), bmat.stride(0), M * N
+    check(lib.ur_conv2d_nhwc(d, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu=False, out=None):
+    """x: [N,H,W,C] (or [N,HW,C]) bf16.  gamma/beta fp32 [C] or None (InstanceNorm when groups == C)."""
+    assert x.dtype == BF16 and x.is_contiguous()
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    out = torch.empty_like(x) if out is None else out
+    ws = _gn_ws(x.device, lib.ur_groupnorm_ws_bytes(n, c))
+    check(lib.ur_groupnorm_nhwc(x.data_ptr(), out.data_ptr(), _ptr(gamma), _ptr(beta), n, hw, c, groups, eps, int(silu),
+                                ws.data_ptr(), _stream()))
+    return out
+
+
+def layer_norm(x: torch.Tensor, gamma, beta, eps: float):
+    assert x.dtype == BF16 and x.is_contiguous()
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib.ur_layernorm_rows(x.data_ptr(), out.data_ptr(), _ptr(gamma), _ptr(beta), x.numel() // c, c, eps, _stream()))
+    return out
+
+
+def softmax_rows(s: torch.Tensor, ldp=None):
+    """s: [..., cols] fp32 -> bf16 probabilities [..., ldp] (columns >= cols are zero)."""
+    cols = s.shape[-1]
+    ldp = ldp or round_up(cols, 8)
+    p = torch.empty((*s.shape[:-1], ldp), dtype=BF16, device=s.device)
+    check(lib.ur_softmax_rows_f32(s.data_ptr(), p.data_ptr(), s.numel() // cols, cols, ldp, _stream()))
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention(q, k, vt, heads: int, head_dim: int, tq: int, tk: int, scale: float, *, ldq, ldk, bs_q, bs_k, bs_vt,
+              batch: int, out=None):
+    """q:[B,Tq,ldq] k:[B?,Tk,ldk] vt:[B?,H*D,ldvt] (raw tensors; strides given explicitly) -> o [B,Tq,H*D]."""
+    c = heads * head_dim
+    out = torch.empty((batch, tq, c), dtype=BF16, device=q.device) if out is None else out
+    check(lib.ur_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, tq, tk, head_dim,
+                               ldq, ldk, vt.shape[-1], c, bs_q, bs_k, bs_vt, tq * c, scale, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ misc
+def dwconv3x3(x, w9c, bias, gate=False):
+    n, h, w_, c = x.shape
+    out = torch.empty((n, h, w_, c // 2 if gate else c), dtype=BF16, device=x.device)
+    check(lib.ur_dwconv3x3_nhwc(x.data_ptr(), w9c.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w_, c, int(gate), _stream()))
+    return out
+
+
+def avgpool(x):
+    n, c = x.shape[0], x.shape[-1]
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(lib.ur_avgpool_hw(x.data_ptr(), out.data_ptr(), n, x.numel() // (n * c), c, _stream()))
+    return out
+
+
+def scale_channels(x, s, residual=None):
+    n, c = x.shape[0], x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib.ur_scale_channels(x.data_ptr(), s.data_ptr(), _ptr(residual), out.data_ptr(), n, x.numel() // (n * c), c, _stream()))
+    return out
+
+
+def axpy_channels(a, b, s):
+    c = a.shape[-1]
+    out = torch.empty_like(a)
+    check(lib.ur_axpy_channels(a.data_ptr(), b.data_ptr(), s.data_ptr(), out.data_ptr(), a.numel() // c, c, _stream()))
+    return out
+
+
+def linear_f32(x, w, bias, act=UR_ACT_NONE, groups=1):
+    """x [M,K] fp32, w [N,K/groups] fp32 -> [M,N] fp32."""
+    m, k = x.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    check(lib.ur_linear_f32(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), m, n, k, groups, act, _stream()))
+    return out
+
+
+def tfa_prompt_update(pooled, cond):
+    b, t, d = cond.shape
+    upd = torch.empty_like(cond)
+    check(lib.ur_tfa_prompt_update(pooled.data_ptr(), cond.data_ptr(), upd.data_ptr(), b, t, d, _stream()))
+    return upd
+
+
+def vec_mul_group(a, b, groups):
+    out = torch.empty_like(a)
+    check(lib.ur_vec_mul_group(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], a.shape[1], groups, _stream()))
+    return out
+
+
+def nchw_to_nhwc(x: torch.Tensor, cpad=None, image=False):
+    """fp32 NCHW -> bf16 NHWC (channels zero-padded to a multiple of 8); image=True applies x*2-1."""
+    x = x.contiguous().float()
+    n, c, h, w_ = x.shape
+    cpad = cpad or round_up(c, 8)
+    out = torch.empty((n, h, w_, cpad), dtype=BF16, device=x.device)
+    fn = lib.ur_image_to_nhwc if image else lib.ur_nchw_f32_to_nhwc
+    check(fn(x.data_ptr(), out.data_ptr(), n, c, h, w_, cpad, _stream()))
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, c=None, mul=1.0, add=0.0):
+    n, h, w_, ld = x.shape
+    c = c or ld
+    out = torch.empty((n, c, h, w_), dtype=torch.float32, device=x.device)
+    check(lib.ur_nhwc_to_nchw_f32(x.data_ptr(), int(x.dtype == torch.float32), out.data_ptr(), n, c, h, w_, ld, mul, add, _stream()))
+    return out
+
+
+def vae_sample(moments_f32, noise_nchw, clat, scale):
+    n, h, w_, ld = moments_f32.shape
+    z = torch.empty((n, h, w_, 8), dtype=torch.float32, device=moments_f32.device)
+    zb = torch.empty((n, h, w_, 8), dtype=BF16, device=moments_f32.device)
+    check(lib.ur_vae_sample(moments_f32.data_ptr(), ld, noise_nchw.data_ptr(), z.data_ptr(), zb.data_ptr(), n, h * w_, clat, 8,
+                            scale, _stream()))
+    return z, zb
+
+
+def add_noise(z0, noise_nchw, clat, sa, sb):
+    n, h, w_, cp = z0.shape
+    zt, zb = torch.empty_like(z0), torch.empty(z0.shape, dtype=BF16, device=z0.device)
+    check(lib.ur_add_noise(z0.data_ptr(), noise_nchw.data_ptr(), zt.data_ptr(), zb.data_ptr(), n, h * w_, clat, cp, sa, sb, _stream()))
+    return zt, zb
+
+
+def ddim_step_(zt, zt_bf16, eps_f32, clat, c_x, c_e):
+    cp = zt.shape[-1]
+    check(lib.ur_ddim_step(zt.data_ptr(), eps_f32.data_ptr(), eps_f32.shape[-1], zt_bf16.data_ptr(), zt.numel() // cp, clat, cp,
+                           c_x, c_e, _stream()))
+
+
+def f32_to_bf16(x, c, mul=1.0, cpad=8):
+    ld = x.shape[-1]
+    out = torch.empty((*x.shape[:-1], cpad), dtype=BF16, device=x.device)
+    check(lib.ur_f32_to_bf16_scaled(x.data_ptr(), ld, out.data_ptr(), x.numel() // ld, c, cpad, mul, _stream()))
+    return out
+
+
+def profile_enable(on: bool):
+    check(lib.ur_profile_enable(int(on)))
+
+
+def profile_report() -> dict:
+    import ctypes
+    import json
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(lib.ur_profile_report(buf, len(buf)))
+    return json.loads(buf.value.decode())
