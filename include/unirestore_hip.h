@@ -59,7 +59,8 @@ typedef struct ur_conv_desc {
   const void* residual; /* bf16 [M, ldr] or NULL (M = N*OH*OW) */
   void* y;              /* bf16 (or fp32 if out_f32) [M, ldy]; may be NULL if only colsum is wanted */
   void* yt;             /* bf16 transposed output for columns >= n_split: [M/t_rows][Cout-n_split][t_ld] or NULL */
-  float* colsum;        /* fp32 [N][Cout_out] += colsum_scale * sum over the image's rows (atomic) or NULL */
+  float* colsum;        /* fp32 [N][nbatch*Cout_out] += colsum_scale * sum over the image's rows (atomic; fused
+                           AdaptiveAvgPool2d(1), taskeditor.py:35) or NULL; batch index = channel group */
   float* workspace;     /* fp32 split-K scratch or NULL */
   size_t workspace_bytes;
   int N, H, W;          /* input dims (before upsample2x) */
@@ -75,6 +76,8 @@ typedef struct ur_conv_desc {
   float colsum_scale;
   int nbatch;           /* >= 1 */
   long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r; /* element strides per batch index */
+  long long bias_img_stride; /* 0: one bias row; else bias row of image n = m/(OH*OW) is bias + n*stride
+                                (per-sample time embeddings, unifie.py:91-105) */
 } ur_conv_desc;
 
 int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream);
@@ -86,8 +89,10 @@ int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream);
  * ws: fp32 scratch of ur_groupnorm_ws_bytes(N, C) bytes.
  */
 size_t ur_groupnorm_ws_bytes(int N, int C);
-int ur_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C,
-                      int G, float eps, int silu, void* ws, ur_stream_t stream);
+/* x2/C2 (optional): second source tensor, virtually concatenated after x's C1 channels (UNet up path:
+ * GroupNorm over torch.cat([sample, skip]), base_model.py:189,197); y is [N,HW,C1+C2]. */
+int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int N, int HW,
+                      int C1, int C2, int G, float eps, int silu, void* ws, ur_stream_t stream);
 /* LayerNorm over the last dim of [rows, C] bf16 (nn.LayerNorm in BasicTransformerBlock; timm LayerNorm2d
  * in NAFBlock, nafnet_arch.py:97-98, which is LayerNorm-over-C in NHWC). */
 int ur_layernorm_rows(const void* x, void* y, const float* gamma, const float* beta, long long rows, int C,

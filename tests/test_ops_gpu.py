@@ -237,3 +237,21 @@ def test_error_convention(ops):
     pc = ops.pack_conv(torch.zeros(8, 16, 3, 3), None, "cuda")
     with pytest.raises((ValueError, AssertionError)):
         ops.conv(x, pc)
+
+
+def test_groupnorm_virtual_concat(ops):
+    """GroupNorm over cat([a, b]) with a group straddling the boundary (1280+640 -> 60 ch/group in the UNet)."""
+    g = _gen(12)
+    a = _rb(torch.randn(2, 128, 8, 8, generator=g)); b = _rb(torch.randn(2, 64, 8, 8, generator=g) * 2 + 1)
+    ga, be = torch.randn(192, generator=g), torch.randn(192, generator=g)
+    ref = F.silu(F.group_norm(torch.cat([a, b], 1), 32, ga, be, eps=1e-5))      # 6 channels / group
+    y = ops.group_norm(_nhwc(a), ga.cuda(), be.cuda(), 32, 1e-5, True, x2=_nhwc(b))
+    assert rel_l2(_nchw(y), ref) < TOL_BF16
+
+
+def test_conv_per_image_bias(ops):
+    g = _gen(13)
+    x = _rb(torch.randn(3, 32, 8, 8, generator=g)); wt = _rb(torch.randn(64, 32, 3, 3, generator=g) / 17)
+    bi = torch.randn(3, 64, generator=g)
+    y = ops.conv(_nhwc(x), ops.pack_conv(wt, None, "cuda"), bias=bi.cuda())
+    assert rel_l2(_nchw(y), F.conv2d(x, wt, padding=1) + bi[:, :, None, None]) < TOL_BF16

@@ -58,6 +58,9 @@ namespace ur {
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 int check_launch(const char* what);
+// Zero `bytes` (multiple of 4) with a kernel node: hipMemsetAsync memset nodes misbehaved under hipGraph
+// replay on small private-pool buffers (ROCm 7.2), so the library never emits memset nodes.
+void zero_async(void* ptr, size_t bytes, hipStream_t s);
 
 // Live timing: one (start, stop) hipEvent pair around each launch, on the launch stream.
 struct ProfScope {

@@ -265,7 +265,7 @@ int ur_avgpool_hw(const void* x, float* out, int N, int HW, int C, ur_stream_t s
   UR_REQUIRE(x && out && C % 8 == 0, "bad args");
   hipStream_t s = (hipStream_t)stream;
   ur::ProfScope prof("avgpool", 0.0, 2.0 * N * (double)HW * C, s);
-  hipMemsetAsync(out, 0, (size_t)N * C * sizeof(float), s);
+  ur::zero_async(out, (size_t)N * C * sizeof(float), s);
   int chunks = (int)std::min<long long>(std::max<long long>(1, (1024 + N - 1) / N), (HW + 31) / 32);
   int ppb = (HW + chunks - 1) / chunks;
   chunks = (HW + ppb - 1) / ppb;

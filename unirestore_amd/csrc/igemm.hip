@@ -23,7 +23,7 @@ struct ConvK {
   int ups, act, out_f32, n_split, t_rows, t_ld;
   float out_scale, colsum_scale;
   int M, Ktot, nk, tiles_m, tiles_n, splitk, nk_per_split, nbatch;
-  long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r;
+  long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r, bias_img;
   size_t ws_bytes_;
 };
 
@@ -57,9 +57,10 @@ __device__ __forceinline__ void epi_store(const ConvK& p, int gb, int m, int co,
 
 // bias + activation + scale on a quad; `g` is the gate quad for pair activations. co_in = column in the
 // GEMM's N space (pre-pairing); returns the output column.
-__device__ __forceinline__ int epi_act(const ConvK& p, int gb, int co_in, float a[4], const float g[4]) {
+__device__ __forceinline__ int epi_act(const ConvK& p, int gb, int m, int co_in, float a[4], const float g[4]) {
+  const long long boff = gb * p.bs_bias + (p.bias_img ? (long long)(m / p.OHW) * p.bias_img : 0);
   if (p.bias) {
-    const float* b = p.bias + gb * p.bs_bias + co_in;
+    const float* b = p.bias + boff + co_in;
     float4 bv = *reinterpret_cast<const float4*>(b);
     a[0] += bv.x; a[1] += bv.y; a[2] += bv.z; a[3] += bv.w;
   }
@@ -67,7 +68,7 @@ __device__ __forceinline__ int epi_act(const ConvK& p, int gb, int co_in, float 
   if (is_pair_act(p.act)) {
     float gg[4] = {g[0], g[1], g[2], g[3]};
     if (p.bias) {
-      float4 bv = *reinterpret_cast<const float4*>(p.bias + gb * p.bs_bias + co_in + 32);
+      float4 bv = *reinterpret_cast<const float4*>(p.bias + boff + co_in + 32);
       gg[0] += bv.x; gg[1] += bv.y; gg[2] += bv.z; gg[3] += bv.w;
     }
 #pragma unroll
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
           for (int e = 0; e < 4; ++e) g[e] = acc[(a + a1) % FN][b][rg * 4 + e];
         }
         int co = co_in;
-        if (ok) co = epi_act(p, gb, co_in, v, g);
+        if (ok) co = epi_act(p, gb, m, co_in, v, g);
         if (p.colsum) {  // per-image column sums of the activated output (all 32 lanes share co)
           int mclamp = min(m, p.M - 1);
           int img = mclamp / p.OHW;
@@ -279,8 +280,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
             s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
             if (mrow == 0 && co_in < p.Cout) {
-              int cw = pair ? p.Cout / 2 : p.Cout;
-              atomicAdd(p.colsum + ((long long)gb * p.N + img) * cw + co + e, s * p.colsum_scale);
+              int cw = pair ? p.Cout / 2 : p.Cout;   // colsum is [N][nbatch*cw]: batch index = channel group
+              atomicAdd(p.colsum + ((long long)img * p.nbatch + gb) * cw + co + e, s * p.colsum_scale);
             }
           }
         }
@@ -310,11 +311,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p) {
         g[0] += u.x; g[1] += u.y; g[2] += u.z; g[3] += u.w;
       }
     }
-    int co = epi_act(p, gb, co_in, v, g);
+    int co = epi_act(p, gb, m, co_in, v, g);
     if (p.colsum) {
       int cw = pair ? p.Cout / 2 : p.Cout;
       for (int e = 0; e < 4; ++e)
-        atomicAdd(p.colsum + ((long long)gb * p.N + m / p.OHW) * cw + co + e, v[e] * p.colsum_scale);
+        atomicAdd(p.colsum + ((long long)(m / p.OHW) * p.nbatch + gb) * cw + co + e, v[e] * p.colsum_scale);
     }
     epi_store(p, gb, m, co, v);
   }
@@ -382,7 +383,7 @@ extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
   k.n_split = d->yt ? d->n_split : d->Cout; k.t_rows = d->t_rows; k.t_ld = d->t_ld;
   k.out_scale = d->out_scale; k.colsum_scale = d->colsum_scale;
   k.M = d->N * d->OH * d->OW; k.Ktot = d->KH * d->KW * k.Cin; k.nk = (k.Ktot + 63) / 64; k.nbatch = d->nbatch;
-  k.bs_x = d->bs_x; k.bs_x2 = d->bs_x2; k.bs_w = d->bs_w; k.bs_bias = d->bs_bias; k.bs_y = d->bs_y; k.bs_r = d->bs_r;
+  k.bs_x = d->bs_x; k.bs_x2 = d->bs_x2; k.bs_w = d->bs_w; k.bs_bias = d->bs_bias; k.bs_y = d->bs_y; k.bs_r = d->bs_r; k.bias_img = d->bias_img_stride;
   UR_REQUIRE(k.M > 0, "empty problem");
 
   hipStream_t s = (hipStream_t)stream;

@@ -8,13 +8,13 @@ namespace {
 // grid = (chunks, N).  Thread (r, v): channel vector v (8 channels), pixel rows r, r+R, ...  Block partials
 // are combined in LDS and leave as one fp64 atomic per channel per block.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ x, double* __restrict__ stats,
-                                                       int HW, int C, int pix_per_block) {
+                                                       int HW, int C, int pix_per_block, int c_off, int C_total) {
   extern __shared__ float lds[];  // [2][C] when CV <= 256
   const int n = blockIdx.y, t = threadIdx.x;
   const int CV = C >> 3;
   const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
   const uint16_t* xi = x + (long long)n * HW * C;
-  double* st = stats + (long long)n * C * 2;
+  double* st = stats + ((long long)n * C_total + c_off) * 2;
   if (CV <= 256) {
     const int R = 256 / CV;
     for (int i = t; i < 2 * C; i += 256) lds[i] = 0.f;
@@ -63,12 +63,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
                                                        const double* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int HW, int C, int G, float eps,
-                                                       int silu, int pix_per_block) {
+                                                       int silu, int pix_per_block, int c_off, int C_total) {
+  // C = channels of THIS source tensor; it occupies channels [c_off, c_off+C) of the C_total-wide (virtually
+  // concatenated) normalisation domain; y has row stride C_total.
   extern __shared__ float lds[];  // a[C], b[C]
   const int n = blockIdx.y, t = threadIdx.x;
-  const int cpg = C / G;
-  const double* st = stats + (long long)n * C * 2;
-  for (int c = t; c < C; c += 256) {
+  const int cpg = C_total / G;
+  const double* st = stats + (long long)n * C_total * 2;
+  for (int cl = t; cl < C; cl += 256) {
+    const int c = c_off + cl;
     const int g0 = (c / cpg) * cpg;
     double s = 0.0, q = 0.0;
     for (int j = 0; j < cpg; ++j) { s += st[2 * (g0 + j)]; q += st[2 * (g0 + j) + 1]; }
@@ -78,16 +81,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     var = var < 0.0 ? 0.0 : var;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    lds[c] = rstd * ga;
-    lds[C + c] = be - (float)mean * rstd * ga;
+    lds[cl] = rstd * ga;
+    lds[C + cl] = be - (float)mean * rstd * ga;
   }
   __syncthreads();
   const int CV = C >> 3;
   const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
   const long long base = (long long)n * HW * C;
+  const long long obase = (long long)n * HW * C_total + c_off;
   const long long v_begin = (long long)p_begin * CV, v_end = (long long)p_end * CV;
   for (long long i = v_begin + t; i < v_end; i += 256) {
     const int v = (int)(i % CV);
+    const long long pix = i / CV;
     uint4 raw = *reinterpret_cast<const uint4*>(x + base + i * 8);
     float f[8];
     unpack8(raw, f);
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
       float o = f[e] * lds[v * 8 + e] + lds[C + v * 8 + e];
       f[e] = silu ? silu_f(o) : o;
     }
-    *reinterpret_cast<uint4*>(y + base + i * 8) = pack8(f);
+    *reinterpret_cast<uint4*>(y + obase + pix * C_total + v * 8) = pack8(f);
   }
 }
 
@@ -178,23 +183,30 @@ extern "C" {
 
 size_t ur_groupnorm_ws_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(double); }
 
-int ur_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int G,
-                      float eps, int silu, void* ws, ur_stream_t stream) {
+int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int N, int HW,
+                      int C1, int C2, int G, float eps, int silu, void* ws, ur_stream_t stream) {
   UR_REQUIRE(x && y && ws, "null pointer");
-  UR_REQUIRE(C % 8 == 0 && G > 0 && C % G == 0 && N > 0 && HW > 0, "C%8, C%G");
+  const int C = C1 + (x2 ? C2 : 0);
+  UR_REQUIRE(C1 % 8 == 0 && (!x2 || C2 % 8 == 0) && G > 0 && C % G == 0 && N > 0 && HW > 0, "C%8, C%G");
   UR_REQUIRE((size_t)C * 8 <= 64 * 1024, "C too large");
   hipStream_t s = (hipStream_t)stream;
   const double bytes = 2.0 * N * HW * (double)C;
   ur::ProfScope prof("groupnorm", 0.0, 3.0 * bytes, s);
-  hipMemsetAsync(ws, 0, ur_groupnorm_ws_bytes(N, C), s);
+  ur::zero_async(ws, ur_groupnorm_ws_bytes(N, C), s);
   // enough blocks to fill 256 CUs several times over, at least ~32 pixels per block
   int chunks = (int)std::min<long long>(std::max<long long>(1, (2048 + N - 1) / N), (HW + 31) / 32);
   int ppb = (HW + chunks - 1) / chunks;
   chunks = (HW + ppb - 1) / ppb;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, N), dim3(256), (size_t)2 * C * sizeof(float), s,
-                     (const uint16_t*)x, (double*)ws, HW, C, ppb);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, N), dim3(256), (size_t)2 * C * sizeof(float), s, (const uint16_t*)x,
-                     (uint16_t*)y, (const double*)ws, gamma, beta, HW, C, G, eps, silu, ppb);
+  const uint16_t* src[2] = {(const uint16_t*)x, (const uint16_t*)x2};
+  const int cs[2] = {C1, x2 ? C2 : 0}, off[2] = {0, C1};
+  for (int i = 0; i < 2; ++i)
+    if (cs[i] > 0)
+      hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, N), dim3(256), (size_t)2 * cs[i] * sizeof(float), s, src[i],
+                         (double*)ws, HW, cs[i], ppb, off[i], C);
+  for (int i = 0; i < 2; ++i)
+    if (cs[i] > 0)
+      hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, N), dim3(256), (size_t)2 * cs[i] * sizeof(float), s, src[i],
+                         (uint16_t*)y, (const double*)ws, gamma, beta, HW, cs[i], G, eps, silu, ppb, off[i], C);
   return ur::check_launch("ur_groupnorm_nhwc");
 }
 

@@ -7,7 +7,20 @@
 
 #include "common.h"
 
+namespace {
+__global__ void zero_kernel(uint32_t* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+
 namespace ur {
+
+void zero_async(void* ptr, size_t bytes, hipStream_t s) {
+  const size_t n = bytes / 4;
+  if (n == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t*)ptr, n);
+}
 
 static thread_local std::string g_err;
 

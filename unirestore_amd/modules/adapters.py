@@ -1,0 +1,193 @@
+"""UniRestore's adapters on the HIP ops: CSCEAdapter (SC-Tuner), NAFBlock / AdaNAFV2 (CFRM), TaskFeatureAdapter (TFA).
+
+Same constructor signatures, parameter names and forward semantics as the reference classes
+(scedit.py:24-38, nafnet_arch.py:28-131, cfrm.py:12-54, taskeditor.py:10-108); `forward` takes/returns NCHW fp32
+tensors like the reference operators, `run` is the NHWC bf16 fast path the model graph uses.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import UR_ACT_GATE, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_TANH
+from .nn import DEV, Conv2d, LayerNorm, Linear, GroupNorm
+
+
+def _named(**mods):
+    return nn.ModuleDict({k.lstrip("_"): v for k, v in mods.items()})
+
+
+def _to_nhwc(x):
+    return ops.nchw_to_nhwc(x.to(DEV))
+
+
+class CSCEAdapter(nn.Module):
+    """out = tuner(x + proj(cond)) + proj(cond) + x, as 3 GEMMs with the adds in their epilogues."""
+
+    def __init__(self, c_in, c_emb, c_cond):
+        super().__init__()
+        self.proj = Conv2d(c_cond, c_in, 1)
+        self.tuner = _named(_0=Conv2d(c_in, c_emb, 1), _2=Conv2d(c_emb, c_in, 1))
+
+    def run(self, x, condition):
+        s = ops.conv(condition, self.proj.packed(), residual=x)               # s = x + proj(cond)
+        h = ops.conv(s, self.tuner["0"].packed(), act=UR_ACT_GELU)
+        return ops.conv(h, self.tuner["2"].packed(), residual=s)              # tuner(s) + s
+
+    def forward(self, x, condition):
+        return ops.nhwc_to_nchw(self.run(_to_nhwc(x), _to_nhwc(condition)), c=x.shape[1])
+
+
+class LayerNorm2d(LayerNorm):
+    """LayerNorm over C of an image tensor; in NHWC that is a plain row LayerNorm (eps 1e-6, timm)."""
+
+    def __init__(self, c):
+        super().__init__(c, eps=1e-6)
+
+
+class NAFBlock(nn.Module):
+    def __init__(self, c, DW_Expand=2, FFN_Expand=2, drop_out_rate=0.0):
+        super().__init__()
+        assert DW_Expand == 2 and FFN_Expand == 2 and drop_out_rate == 0.0
+        self.conv1 = Conv2d(c, 2 * c, 1)
+        self.conv2 = Conv2d(2 * c, 2 * c, 3, padding=1, groups=2 * c)
+        self.conv3 = Conv2d(c, c, 1)
+        self.sca = _named(_1=Conv2d(c, c, 1))
+        self.conv4 = Conv2d(c, 2 * c, 1)
+        self.conv5 = Conv2d(c, c, 1)
+        self.norm1, self.norm2 = LayerNorm2d(c), LayerNorm2d(c)
+        self.beta = nn.Parameter(torch.zeros(1, c, 1, 1))
+        self.gamma = nn.Parameter(torch.zeros(1, c, 1, 1))
+
+    def _dw(self):
+        if "dw" not in self.__dict__:
+            c2 = self.conv2.weight.shape[0]
+            self.__dict__["dw"] = (self.conv2.weight.detach().float().view(c2, 9).t().contiguous().to(DEV),
+                                   self.conv2.bias.detach().float().to(DEV),
+                                   self.sca["1"].weight.detach().float().view(c2 // 2, c2 // 2).contiguous().to(DEV),
+                                   self.sca["1"].bias.detach().float().to(DEV))
+        return self.__dict__["dw"]
+
+    def run(self, inp):
+        w9c, b2, wsca, bsca = self._dw()
+        x = ops.conv(self.norm1.run(inp), self.conv1.packed())
+        x = ops.dwconv3x3(x, w9c, b2, gate=True)                               # depthwise + SimpleGate
+        s = ops.linear_f32(ops.avgpool(x), wsca, bsca)                         # simplified channel attention
+        x = ops.scale_channels(x, s)
+        y = ops.conv(x, self.conv3.packed(scale=self.beta), residual=inp)      # inp + conv3(x)*beta (beta folded)
+        x = ops.conv(self.norm2.run(y), self.conv4.packed(pair=True), act=UR_ACT_GATE)
+        return ops.conv(x, self.conv5.packed(scale=self.gamma), residual=y)    # y + conv5(x)*gamma
+
+    def forward(self, inp):
+        return ops.nhwc_to_nchw(self.run(_to_nhwc(inp)), c=inp.shape[1])
+
+
+class AdaNAFV2(nn.Module):
+    GROUPS = 16
+
+    def __init__(self, c, DW_Expand=2, FFN_Expand=2, drop_out_rate=0.0):
+        super().__init__()
+        g, w = self.GROUPS, 4 * c
+        self.conv_in = Conv2d(c, w, 1)
+        self.group_norm = GroupNorm(g, w)
+        self.group_conv = Conv2d(w, w, 3, padding=1, groups=g)
+        self.intra_group_attn = _named(_1=Conv2d(w, w, 1, groups=g))
+        self.inter_group_attn = _named(_1=Conv2d(w, g, 1))
+        self.pwconv = Conv2d(w, c, 1)
+        self.nafblock = NAFBlock(c, DW_Expand, FFN_Expand, drop_out_rate)
+
+    def _vecs(self):
+        if "vecs" not in self.__dict__:
+            ia, ie = self.intra_group_attn["1"], self.inter_group_attn["1"]
+            self.__dict__["vecs"] = (ia.weight.detach().float().flatten(1).contiguous().to(DEV), ia.bias.detach().float().to(DEV),
+                                     ie.weight.detach().float().flatten(1).contiguous().to(DEV), ie.bias.detach().float().to(DEV))
+        return self.__dict__["vecs"]
+
+    def run(self, inp):
+        g = self.GROUPS
+        wia, bia, wie, bie = self._vecs()
+        x = self.group_norm.run(ops.conv(inp, self.conv_in.packed()))
+        x = ops.conv(x, self.group_conv.packed(), act=UR_ACT_GELU)             # grouped 3x3 (+GELU)
+        pooled = ops.avgpool(x)
+        s_intra = ops.linear_f32(pooled, wia, bia, groups=g)                   # per-channel scale
+        pooled2 = ops.vec_mul_group(pooled, s_intra, s_intra.shape[1])         # mean(x*s) = s*mean(x)
+        iga = ops.linear_f32(pooled2, wie, bie)                                # per-group scale
+        x = ops.scale_channels(x, ops.vec_mul_group(s_intra, iga, g))
+        return self.nafblock.run(ops.conv(x, self.pwconv.packed(), residual=inp))
+
+    def forward(self, inp):
+        return ops.nhwc_to_nchw(self.run(_to_nhwc(inp)), c=inp.shape[1])
+
+
+class _Seq(nn.Sequential):
+    def run(self, x):
+        for m in self:
+            x = m.run(x)
+        return x
+
+    def forward(self, x):
+        return ops.nhwc_to_nchw(self.run(_to_nhwc(x)), c=x.shape[1])
+
+
+def cfrm_blocks(channels=(128, 256, 512), depths=(1, 1, 9)) -> nn.ModuleList:
+    """fr_blocks wiring (autoencoder.py:91-98)."""
+    return nn.ModuleList([_Seq(*[NAFBlock(c) for _ in range(n)], AdaNAFV2(c)) for c, n in zip(channels, depths)])
+
+
+class TaskFeatureAdapter(nn.Module):
+    def __init__(self, c_out=512, c_skip=256, prompt_len=1, last_layer=False):
+        super().__init__()
+        d = c_skip
+        self.prompt_dim, self.prompt_len, self.last_layer = d, prompt_len, last_layer
+        self.t_gate1 = Conv2d(c_skip, d, 1)
+        self.t_gate2 = Conv2d(d, c_skip, 1)
+        self.conv_out = Conv2d(c_skip + c_out, c_out, 1)
+
+        def gate():
+            return _named(_1=Conv2d(c_skip, c_skip, 3, padding=1), _3=Conv2d(c_skip, d * prompt_len, 3, padding=1))
+
+        self.filter_gate, self.info_gate, self.content_trans = gate(), gate(), gate()
+        self.out_gate = _named(_0=Linear(d * prompt_len, d))
+        if not last_layer:
+            self.prompt_trans = _named(_0=Linear(d, d // 2))
+
+    def _fused(self):
+        """The three gate branches share their input: stage 1 = one conv with 3x the output channels,
+        stage 2 = one grouped conv (3 groups) whose epilogue is the global average pool."""
+        if "fused" not in self.__dict__:
+            br = (self.filter_gate, self.info_gate, self.content_trans)
+            w1 = torch.cat([b["1"].weight.detach().float() for b in br], 0)
+            b1 = torch.cat([b["1"].bias.detach().float() for b in br], 0)
+            w2 = torch.cat([b["3"].weight.detach().float() for b in br], 0)
+            b2 = torch.cat([b["3"].bias.detach().float() for b in br], 0)
+            self.__dict__["fused"] = (ops.pack_conv(w1, b1, DEV), ops.pack_conv(w2, b2, DEV, groups=3))
+        return self.__dict__["fused"]
+
+    def run(self, x, skip, condition):
+        """x [B,h,w,c_out], skip [B,h,w,c_skip] bf16 NHWC; condition fp32 [B,T,D] -> (x', cond' or None)."""
+        b, hh, ww, cs = skip.shape
+        pc1, pc2 = self._fused()
+        sn = ops.group_norm(skip, None, None, cs, 1e-5)                        # InstanceNorm2d (no affine)
+        h3 = ops.conv(sn, pc1, act=UR_ACT_GELU)
+        pooled = torch.zeros((b, pc2.cout_out), dtype=torch.float32, device=skip.device)
+        if (hh * ww) % 32 == 0:
+            ops.conv(h3, pc2, colsum=pooled, colsum_scale=1.0 / (hh * ww))     # conv + AdaptiveAvgPool2d(1), no store
+        else:
+            pooled = ops.avgpool(ops.conv(h3, pc2))
+        upd = ops.tfa_prompt_update(pooled, condition.contiguous())
+        wo, bo = self.out_gate["0"].dev_f32()
+        o = ops.linear_f32(upd.view(b, -1), wo, bo, UR_ACT_TANH)               # [B, D]
+        hs = ops.scale_channels(ops.conv(skip, self.t_gate1.packed()), o)
+        skip2 = ops.conv(hs, self.t_gate2.packed(), residual=skip)
+        x = ops.conv(x, self.conv_out.packed(), x2=skip2, residual=x)          # x + conv_out(cat[x, skip])
+        new_cond = None
+        if not self.last_layer:
+            wp, bp = self.prompt_trans["0"].dev_f32()
+            new_cond = ops.linear_f32(upd.view(b * self.prompt_len, -1), wp, bp, UR_ACT_GELU).view(b, self.prompt_len, -1)
+        return x, new_cond
+
+    def forward(self, x, skip, condition):
+        y, c = self.run(_to_nhwc(x), _to_nhwc(skip), condition.to(DEV).float())
+        return ops.nhwc_to_nchw(y, c=x.shape[1]), c
+
+
+TaskEditorV1c = TaskFeatureAdapter     # the reference imports it under this stale name (autoencoder.py:112)

@@ -1,0 +1,399 @@
+"""Model graph of the hot path on the HIP ops: Controller, ControlledUNet, SkipConnectedAutoEncoder, DiffUIE.
+
+Mirrors the reference operator interface (names, constructor arguments, attribute paths, error behaviour):
+  DiffUIE                    /root/reference/src/modules/diffuie/unifie.py:22-169
+  SkipConnectedAutoEncoder   /root/reference/src/modules/diffuie/autoencoder.py:74-184 (+ patched forwards :11-72)
+  Controller                 /root/reference/src/modules/diffuie/controller.py:65-220
+  ControlledUNet             /root/reference/src/modules/diffuie/base_model.py:13-245
+MI355X-first differences (results unchanged): NHWC bf16 activations, per-schedule time-embedding tables folded
+into conv biases, constant cross-attention K/V computed once, the whole forward replayed as one hipGraph.
+"""
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops, schedule
+from .adapters import CSCEAdapter, TaskFeatureAdapter, cfrm_blocks
+from .nn import (DEV, AutoencoderKL, Conv2d, DownBlock, MidBlock, ResnetBlock2D, TimestepEmbedding, UNet2DConditionModel,
+                 invalidate_packed, sinusoid_table)
+
+stablesr_config = dict(in_channels=4, model_channels=256, out_channels=256, num_res_blocks=2, dropout=0,
+                       channel_mult=(1, 1, 2, 2), downsample_type="conv", num_heads=4,
+                       down_block_types=("AttnDownBlock2D",) * 3 + ("DownBlock2D",), mid_block_type="UNetMidBlock2D")
+
+
+def _resnets(module):
+    return [m for m in module.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+
+
+class Controller(nn.Module):
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, dropout, channel_mult,
+                 downsample_type, num_heads, down_block_types, mid_block_type, groups=32):
+        super().__init__()
+        if mid_block_type != "UNetMidBlock2D":
+            raise NotImplementedError(mid_block_type)
+        self.model_channels = model_channels
+        temb = model_channels * 4
+        self.time_embedding = TimestepEmbedding(model_channels, temb)
+        self.conv_in = Conv2d(in_channels, model_channels, 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        chans, out = [], model_channels
+        for i, kind in enumerate(down_block_types):
+            cin, out = out, model_channels * channel_mult[i]
+            last = i == len(channel_mult) - 1
+            self.down_blocks.append(DownBlock(cin, out, temb, attn="self" if kind == "AttnDownBlock2D" else None,
+                                              head_dim=out // num_heads, add_downsample=not last,
+                                              layers=num_res_blocks, groups=groups, eps=1e-5))
+            chans.append(out)
+        self.middle_block = MidBlock(out, temb, "self", head_dim=out // num_heads, groups=groups, eps=1e-5)
+        self.fea_tran = nn.ModuleList([ResnetBlock2D(c, out_channels, temb, groups, 1e-5) for c in chans])
+        for m in self.modules():                      # zero-conv init (controller.py:174-185)
+            if isinstance(m, ResnetBlock2D):
+                nn.init.zeros_(m.conv2.weight), nn.init.zeros_(m.conv2.bias)
+            if hasattr(m, "to_out") and hasattr(m, "group_norm"):
+                nn.init.zeros_(m.to_out[0].weight), nn.init.zeros_(m.to_out[0].bias)
+
+    def set_timesteps(self, timesteps):
+        emb = self.time_embedding.silu_emb(sinusoid_table(timesteps, self.model_channels))
+        for r in _resnets(self):
+            r.set_time_table(emb)
+
+    def stem(self, z_bf16):
+        """conv_in(z0) does not depend on t: computed once per image, reused by every step (controller.py:198)."""
+        return ops.conv(z_bf16, self.conv_in.packed())
+
+    def run(self, stem, step):
+        feats, h = [], stem
+        for blk in self.down_blocks:
+            states = []
+            for i, res in enumerate(blk.resnets):
+                h = res.run(h, step=step)
+                if blk.attn_kind == "self":
+                    h = blk.attentions[i].run(h)
+                states.append(h)
+            if blk.downsamplers is not None:
+                h = blk.downsamplers[0].run(h)
+                states.append(h)
+            feats.append(states[-2])                                   # output[-2] (controller.py:205)
+        feats[-1] = self.middle_block.run(h, step=step)                # replace the last one (controller.py:211)
+        return {f.shape[2]: self.fea_tran[i].run(f, step=step) for i, f in enumerate(feats)}   # keyed by WIDTH
+
+    def forward(self, x, timesteps, encoder_hidden_states=None):
+        """Reference signature: x (B,4,h,w) fp32 NCHW, timesteps (1,) or (B,) -> {width: (B,256,h',w') fp32}."""
+        ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
+        if len(set(ts)) != 1:
+            raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
+        self.set_timesteps(ts[:1])
+        out = self.run(self.stem(ops.nchw_to_nhwc(x.to(DEV))), 0)
+        return {k: ops.nhwc_to_nchw(v) for k, v in out.items()}
+
+
+class ControlledUNet(nn.Module):
+    def __init__(self, unet: UNet2DConditionModel, control_type: str, null_embeds: Optional[torch.Tensor] = None,
+                 cond_channels: int = 256):
+        super().__init__()
+        self.unet = unet
+        cross_dim = unet.down_blocks[0].attentions[0].transformer_blocks[0].attn2.to_k.in_features
+        if null_embeds is None:
+            p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "assets", "sd_null_emb.pt")
+            null_embeds = torch.load(p, map_location="cpu") if (cross_dim == 1024 and os.path.exists(p)) else \
+                torch.zeros(1, 77, cross_dim)
+        self.register_buffer("null_embeds", null_embeds.float())
+        if control_type == "spade":
+            raise NotImplementedError("control_type 'spade' is not built yet (SURVEY.md §8f rank 3)")
+        if control_type != "scedit":
+            raise ValueError(f"control_type '{control_type}' not supported")
+        chans = [unet.conv_in.out_channels]
+        for blk in unet.down_blocks:
+            chans += [r.conv2.out_channels for r in blk.resnets]
+            if blk.downsamplers is not None:
+                chans.append(chans[-1])
+        self.csc_editors = nn.ModuleList([CSCEAdapter(c, c, cond_channels) for c in chans])
+
+    def set_timesteps(self, timesteps):
+        u = self.unet
+        emb = u.time_embedding.silu_emb(sinusoid_table(timesteps, u.time_proj_dim))
+        for r in _resnets(u):
+            r.set_time_table(emb)
+
+    def _ctx(self):
+        if "ctx" not in self.__dict__:
+            self.__dict__["ctx"] = self.null_embeds.to(DEV, ops.BF16).contiguous()
+        return self.__dict__["ctx"]
+
+    def run(self, zt_bf16, control, step):
+        """zt_bf16 [B,h,w,8] (latent channels zero-padded), control {width: NHWC bf16} -> eps fp32 [B,h,w,8]."""
+        u, ctx = self.unet, self._ctx()
+        h = ops.conv(zt_bf16, u.conv_in.packed())
+        skips = [h]
+        for blk in u.down_blocks:
+            for i, res in enumerate(blk.resnets):
+                h = res.run(h, step=step)
+                if blk.attn_kind == "cross":
+                    h = blk.attentions[i].run(h, ctx)
+                skips.append(h)
+            if blk.downsamplers is not None:
+                h = blk.downsamplers[0].run(h)
+                skips.append(h)
+        h = u.mid_block.run(h, step=step, ctx=ctx)
+        skips = [ed.run(s, control[s.shape[2]]) for ed, s in zip(self.csc_editors, skips)]      # SC-Tuner (base_model.py:233-238)
+        for blk in u.up_blocks:
+            for i, res in enumerate(blk.resnets):
+                h = res.run(h, x2=skips.pop(), step=step)                                       # virtual torch.cat
+                if blk.attn_kind == "cross":
+                    h = blk.attentions[i].run(h, ctx)
+            if blk.upsamplers is not None:
+                h = blk.upsamplers[0].run(h)
+        h = u.conv_norm_out.run(h, silu=True)
+        return ops.conv(h, u.conv_out.packed(), out_f32=True)
+
+    def forward(self, sample, control, timesteps):
+        """Reference signature (base_model.py:211-245): NCHW fp32 in, eps NCHW fp32 out."""
+        ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
+        if len(set(ts)) != 1:
+            raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
+        self.set_timesteps(ts[:1])
+        ctl = {k: ops.nchw_to_nhwc(v.to(DEV)) for k, v in control.items()}
+        eps = self.run(ops.nchw_to_nhwc(sample.to(DEV)), ctl, 0)
+        return ops.nhwc_to_nchw(eps, c=self.unet.conv_out.out_channels)
+
+
+class SkipConnectedAutoEncoder(nn.Module):
+    def __init__(self, vae: AutoencoderKL, fr_type: Optional[str] = None, tedit: Optional[dict] = None, fr_depths=(1, 1, 9)):
+        super().__init__()
+        self.tedit_dict = tedit
+        self.vae = vae
+        enc_ch = [b.resnets[-1].conv2.out_channels for b in vae.encoder.down_blocks]
+        if fr_type == "CFRM":
+            vae.encoder.fr_blocks = cfrm_blocks(enc_ch[:3], fr_depths)
+        elif fr_type is not None:
+            raise ValueError("Invalid fr_type")
+        if tedit:
+            self.task_list = list(tedit["task"])
+            self.tedit_type = tedit["type"]
+            if self.tedit_type != "TFA":
+                raise KeyError("%s is not defined in the taskeditor!, please select ['TFA']" % self.tedit_type)
+            pl, top = tedit["prompt_len"], enc_ch[-1]
+            vae.decoder.task_prompts = nn.ParameterDict({t: nn.Parameter(torch.zeros(pl, enc_ch[2])) for t in self.task_list})
+            vae.decoder.task_editors = nn.ModuleList([
+                TaskFeatureAdapter(top, enc_ch[2], prompt_len=pl),
+                TaskFeatureAdapter(top, enc_ch[1], prompt_len=pl),
+                TaskFeatureAdapter(top, enc_ch[0], prompt_len=pl, last_layer=True)])
+        else:
+            self.task_list, self.tedit_type = [], None
+
+    # ---- NHWC fast path -------------------------------------------------------------------------------------
+    def encode_run(self, images_dev: torch.Tensor, noise_nchw: torch.Tensor, enable_fr: bool):
+        """images fp32 NCHW in [0,1] on device -> (z fp32 [B,h,w,8], z bf16, [3 NHWC bf16 skip features])."""
+        enc, lat = self.vae.encoder, self.vae.latent_channels
+        h = ops.conv(ops.nchw_to_nhwc(images_dev, image=True), enc.conv_in.packed())            # x*2-1 fused in the layout pass
+        res = []
+        for i, blk in enumerate(enc.down_blocks[:-1]):
+            h = blk.run(h)
+            if enable_fr:
+                h = enc.fr_blocks[i].run(h)
+            res.append(h)
+        h = enc.mid_block.run(enc.down_blocks[-1].run(h))
+        h = ops.conv(enc.conv_norm_out.run(h, silu=True), enc.conv_out.packed())
+        moments = ops.conv(h, self.vae.quant_conv.packed(), out_f32=True)
+        z, zb = ops.vae_sample(moments, noise_nchw, lat, self.vae.config.scaling_factor)
+        return z, zb, res
+
+    def decode_run(self, z_f32: torch.Tensor, res_samples, task: str):
+        dec, lat = self.vae.decoder, self.vae.latent_channels
+        if task not in dec.task_prompts:
+            raise KeyError(task)
+        zb = ops.f32_to_bf16(z_f32, lat, mul=1.0 / self.vae.config.scaling_factor)
+        h = ops.conv(ops.conv(zb, self.vae.post_quant_conv.packed()), dec.conv_in.packed())
+        h = dec.mid_block.run(h)
+        b = z_f32.shape[0]
+        key = ("cache", "prompt", task)
+        if key not in self.__dict__:                           # device copy made once (not inside graph capture)
+            self.__dict__[key] = dec.task_prompts[task].detach().float().to(DEV)
+        cond = self.__dict__[key].unsqueeze(0).expand(b, -1, -1).contiguous()
+        for i, blk in enumerate(dec.up_blocks[:-1]):
+            h, cond = dec.task_editors[i].run(h, res_samples[-i - 1], cond)
+            h = blk.run(h)
+        h = dec.up_blocks[-1].run(h)
+        h = ops.conv(dec.conv_norm_out.run(h, silu=True), dec.conv_out.packed(), out_f32=True)
+        return ops.nhwc_to_nchw(h, c=dec.conv_out.out_channels, mul=0.5, add=0.5)             # (x+1)/2
+
+    # ---- reference signatures ---------------------------------------------------------------------------------
+    def encode(self, images, enable_fr: bool = False, noise=None):
+        images = images.to(DEV).float()
+        b, _, hh, ww = images.shape
+        if noise is None:
+            noise = torch.randn(b, self.vae.latent_channels, hh // 8, ww // 8, device=DEV)
+        z, _, res = self.encode_run(images, noise.to(DEV).float().contiguous(), enable_fr)
+        return ops.nhwc_to_nchw(z, c=self.vae.latent_channels), [ops.nhwc_to_nchw(r) for r in res]
+
+    def decode(self, latents, res_samples, task: str):
+        z = ops.nchw_to_nhwc(latents.to(DEV)).float()
+        return self.decode_run(z.contiguous(), [ops.nchw_to_nhwc(r.to(DEV)) for r in res_samples], task)
+
+    def forward(self, images, task: str):
+        latents, res = self.encode(images, enable_fr=True)
+        return self.decode(latents, res, "ir")
+
+
+def resize_pad_plan(h: int, w: int):
+    """Integer shape arithmetic of unifie.py:121-134 -> (resized_h, resized_w, pad_h, pad_w)."""
+    if h < 512 or w < 512:
+        s = 512 / min(h, w)
+        h, w = round(h * s), round(w * s)
+    return h, w, (64 - h % 64) % 64, (64 - w % 64) % 64
+
+
+class DiffUIE(nn.Module):
+    """forward(images, task) -> restored images, same contract as the reference (fp32 NCHW in [0,1])."""
+
+    def __init__(self, frenc: Optional[dict] = None, cnet: Optional[dict] = None, tedit: Optional[dict] = None, *,
+                 unet_cfg=None, vae_cfg=None, controller_cfg=None, null_embeds=None, fr_depths=(1, 1, 9), use_graph=True):
+        super().__init__()
+        self.fr_type = frenc["type"] if frenc else None
+        self.control_type = cnet["type"] if cnet else None
+        self.tedit = tedit if tedit else None
+        self.ae = SkipConnectedAutoEncoder(AutoencoderKL(**(vae_cfg or {})), self.fr_type, self.tedit, fr_depths)
+        self.use_graph = use_graph
+        self._graphs = {}
+        if self.control_type:
+            ccfg = controller_cfg or stablesr_config
+            self.controller = Controller(**ccfg)
+            self.base_model = ControlledUNet(UNet2DConditionModel(**(unet_cfg or {})), self.control_type, null_embeds,
+                                             ccfg["out_channels"])
+            self.register_buffer("train_timesteps", torch.tensor([249, 499, 749, 999, 999, 999], dtype=torch.int64))
+            self.num_inference_steps = int(cnet["num_inference_steps"])
+            self.timesteps = schedule.ddim_timesteps(self.num_inference_steps)       # host int64, bit-exact
+            self._tables_ready = False
+
+    # ---- weights ------------------------------------------------------------------------------------------------
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.refresh()
+        return r
+
+    def refresh(self):
+        """Drop device copies derived from the fp32 masters (after loading / editing weights)."""
+        invalidate_packed(self)
+        self.base_model.__dict__.pop("ctx", None) if self.control_type else None
+        self._tables_ready = False
+        self._graphs.clear()
+
+    def _prepare(self):
+        if self.control_type and not self._tables_ready:
+            self.controller.set_timesteps(self.timesteps)
+            self.base_model.set_timesteps(self.timesteps)
+            self._tables_ready = True
+
+    # ---- reference helper signatures ------------------------------------------------------------------------------
+    def diffuse(self, latents, timesteps=None, noise=None):
+        latents = latents.to(DEV).float()
+        if timesteps is None:
+            timesteps = self.train_timesteps[torch.randint(0, len(self.train_timesteps), (latents.size(0),))]
+        ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
+        noise = torch.randn_like(latents) if noise is None else noise.to(DEV).float()
+        ac = schedule.alphas_cumprod()
+        outs = []
+        for i, t in enumerate(ts):       # per-sample t (training helper); inference uses one t for the batch
+            z = ops.nchw_to_nhwc(latents[i:i + 1]).float().contiguous()
+            zt, _ = ops.add_noise(z, noise[i:i + 1].contiguous(), latents.shape[1], float(ac[t]) ** 0.5, float(1 - ac[t]) ** 0.5)
+            outs.append(ops.nhwc_to_nchw(zt, c=latents.shape[1]))
+        return torch.cat(outs, 0), noise, torch.as_tensor(ts)
+
+    # ---- the hot path ------------------------------------------------------------------------------------------------
+    def _forward_device(self, images, task, n_vae, n_t):
+        """images fp32 NCHW on device, padded to multiples of 64.  Returns (preds NCHW fp32, z0, zt) (NHWC fp32 latents)."""
+        lat = self.ae.vae.latent_channels
+        z0, z0b, mids = self.ae.encode_run(images, n_vae, enable_fr=self.fr_type is not None)
+        zt = z0
+        if self.control_type:
+            ac = schedule.alphas_cumprod_f64()
+            zt, ztb = ops.add_noise(z0, n_t, lat, float(np.float32(ac[999] ** 0.5)), float(np.float32((1 - ac[999]) ** 0.5)))
+            stem = self.controller.stem(z0b)
+            for i, t in enumerate(self.timesteps):
+                control = self.controller.run(stem, i)
+                eps = self.base_model.run(ztb, control, i)
+                c_x, c_e = schedule.ddim_coefficients(int(t), self.num_inference_steps)
+                ops.ddim_step_(zt, ztb, eps, lat, c_x, c_e)
+        preds = self.ae.decode_run(zt, mids, task)
+        return preds, z0, zt
+
+    @torch.no_grad()
+    def forward(self, images, task: str, noise=None, return_latents=False):
+        """noise = (eps_vae, eps_t999): the two RNG draws of the reference (autoencoder.py:152, unifie.py:87), NCHW fp32."""
+        if task not in self.ae.task_list and self.tedit:
+            raise KeyError(task)
+        images = images.to(DEV).float()
+        org_h, org_w = images.shape[-2:]
+        h, w, pad_h, pad_w = resize_pad_plan(org_h, org_w)
+        if (h, w) != (org_h, org_w):
+            images = F.interpolate(images, (h, w), mode="bicubic", align_corners=False, antialias=False)
+        if pad_h or pad_w:
+            images = F.pad(images, (0, pad_w, 0, pad_h), mode="reflect")
+        images = images.contiguous()
+        b, lat = images.shape[0], self.ae.vae.latent_channels
+        lh, lw = images.shape[2] // 8, images.shape[3] // 8
+        if noise is None:
+            noise = (torch.randn(b, lat, lh, lw, device=DEV), torch.randn(b, lat, lh, lw, device=DEV))
+        n_vae, n_t = (n.to(DEV).float().contiguous() for n in noise)
+        self._prepare()
+        if self.use_graph:
+            preds, z0, zt = self._graph_forward(images, task, n_vae, n_t)
+        else:
+            preds, z0, zt = self._forward_device(images, task, n_vae, n_t)
+        preds = preds[..., :h, :w]
+        if (h, w) != (org_h, org_w):
+            preds = F.interpolate(preds, (org_h, org_w), mode="bicubic", align_corners=False, antialias=False)
+        if return_latents:
+            return preds, ops.nhwc_to_nchw(z0, c=lat), ops.nhwc_to_nchw(zt, c=lat)
+        return preds
+
+    # ---- hipGraph: the whole fixed-length forward (encode, N denoise steps, decode) is one captured graph --------------
+    def _graph_forward(self, images, task, n_vae, n_t):
+        key = (tuple(images.shape), task)
+        g = self._graphs.get(key)
+        if g is None:
+            static = dict(images=images.clone(), n_vae=n_vae.clone(), n_t=n_t.clone())
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                       # warm-up: packs weights, sizes workspaces, sets func attributes
+                self._forward_device(static["images"], task, static["n_vae"], static["n_t"])
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._forward_device(static["images"], task, static["n_vae"], static["n_t"])
+            g = self._graphs[key] = (graph, static, outs)
+        graph, static, outs = g
+        static["images"].copy_(images)
+        static["n_vae"].copy_(n_vae)
+        static["n_t"].copy_(n_t)
+        if os.environ.get("UR_DEBUG_SYNC"):
+            torch.cuda.synchronize()
+        graph.replay()
+        if os.environ.get("UR_DEBUG_SYNC"):
+            torch.cuda.synchronize()
+        return outs
+
+    def predict_z0(self, latents, conditions, timesteps):
+        """unifie.py:91-105 (training-side helper): per-sample timesteps via per-image bias rows."""
+        lat = latents.shape[1]
+        ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
+        if len(ts) == 1:
+            ts = ts * latents.shape[0]
+        self.controller.set_timesteps(ts)
+        self.base_model.set_timesteps(ts)
+        self._tables_ready = False
+        zb = ops.nchw_to_nhwc(latents.to(DEV))
+        cb = ops.nchw_to_nhwc(conditions.to(DEV))
+        outs = []
+        for i, t in enumerate(ts):
+            control = self.controller.run(self.controller.stem(cb[i:i + 1].contiguous()), i)
+            eps = ops.nhwc_to_nchw(self.base_model.run(zb[i:i + 1].contiguous(), control, i), c=lat)
+            a = float(schedule.alphas_cumprod()[t])
+            outs.append((latents[i:i + 1].to(DEV).float() - (1 - a) ** 0.5 * eps) / a ** 0.5)
+        return torch.cat(outs, 0)

@@ -1,0 +1,444 @@
+"""Leaf parameter holders + the SD building blocks, executed through the HIP ops (NHWC bf16).
+
+The classes keep the reference's / HF checkpoints' parameter names so `load_state_dict`
+of the published weights works unchanged; fp32 masters stay on the host, `packed()` builds the bf16
+device copies the kernels read.  Calling a leaf's torch `forward` is an error: there is no eager path.
+
+Block semantics restated from SURVEY.md Appendix C (diffusers 0.29.0 is not vendored in the reference):
+reference call sites are base_model.py:94-209, controller.py:101-170, autoencoder.py:11-72.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_SILU
+
+DEV = "cuda"
+
+
+class _NoEager:
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f"{type(self).__name__}: no eager/PyTorch path exists; use the HIP-backed graph")
+
+
+class Conv2d(_NoEager, nn.Conv2d):
+    def packed(self, pair=False, scale: Optional[torch.Tensor] = None) -> ops.PackedConv:
+        key = ("pk", pair)
+        if key not in self.__dict__:
+            w, b = self.weight, self.bias
+            if scale is not None:                     # fold a per-output-channel scale (NAFBlock beta/gamma)
+                s = scale.detach().reshape(-1)
+                w = w * s[:, None, None, None]
+                b = None if b is None else b * s
+            self.__dict__[key] = ops.pack_conv(w, b, DEV, pair=pair, groups=self.groups)
+        return self.__dict__[key]
+
+
+class Linear(_NoEager, nn.Linear):
+    def packed(self, pair=False) -> ops.PackedConv:
+        key = ("pk", pair)
+        if key not in self.__dict__:
+            self.__dict__[key] = ops.pack_conv(self.weight, self.bias, DEV, pair=pair)
+        return self.__dict__[key]
+
+    def dev_f32(self):
+        if "f32" not in self.__dict__:
+            self.__dict__["f32"] = (self.weight.detach().float().to(DEV).contiguous(),
+                                    None if self.bias is None else self.bias.detach().float().to(DEV).contiguous())
+        return self.__dict__["f32"]
+
+
+class _Affine:
+    def dev(self):
+        if "aff" not in self.__dict__:
+            self.__dict__["aff"] = (self.weight.detach().float().to(DEV).contiguous(),
+                                    self.bias.detach().float().to(DEV).contiguous())
+        return self.__dict__["aff"]
+
+
+class GroupNorm(_NoEager, _Affine, nn.GroupNorm):
+    def run(self, x, silu=False, x2=None):
+        g, b = self.dev()
+        return ops.group_norm(x, g, b, self.num_groups, self.eps, silu, x2=x2)
+
+
+class LayerNorm(_NoEager, _Affine, nn.LayerNorm):
+    def run(self, x):
+        g, b = self.dev()
+        return ops.layer_norm(x, g, b, self.eps)
+
+
+def invalidate_packed(model: nn.Module):
+    """Drop every cached device copy (call after loading new weights)."""
+    for m in model.modules():
+        for k in [k for k in m.__dict__ if k in ("aff", "f32", "dw", "vecs", "fused", "ctx") or
+                  (isinstance(k, tuple) and k[0] in ("pk", "cache"))]:
+            del m.__dict__[k]
+
+
+def sinusoid_table(timesteps, dim: int) -> torch.Tensor:
+    """Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) for a list of integer timesteps -> fp32 [S, dim] = [cos|sin]."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    ang = torch.as_tensor(list(timesteps), dtype=torch.float32).reshape(-1, 1) * freqs.reshape(1, -1)
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim, time_dim):
+        super().__init__()
+        self.linear_1 = Linear(in_dim, time_dim)
+        self.linear_2 = Linear(time_dim, time_dim)
+
+    def silu_emb(self, sin_table: torch.Tensor) -> torch.Tensor:
+        """silu(linear_2(silu(linear_1(sin)))) for all rows: the only form the resnets consume."""
+        w1, b1 = self.linear_1.dev_f32()
+        w2, b2 = self.linear_2.dev_f32()
+        h = ops.linear_f32(sin_table.to(DEV), w1, b1, UR_ACT_SILU)
+        return ops.linear_f32(h, w2, b2, UR_ACT_SILU)
+
+
+# ----------------------------------------------------------------------------------------------- resnet
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_channels=None, groups=32, eps=1e-5):
+        super().__init__()
+        self.norm1 = GroupNorm(groups, cin, eps=eps)
+        self.conv1 = Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = Linear(temb_channels, cout) if temb_channels else None
+        self.norm2 = GroupNorm(groups, cout, eps=eps)
+        self.conv2 = Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = Conv2d(cin, cout, 1) if cin != cout else None
+        self.tbias = None           # fp32 [S or B, cout]: conv1.bias + time_emb_proj(silu(emb)) rows
+
+    def set_time_table(self, silu_emb: torch.Tensor):
+        """Per-row conv1 bias with the time embedding folded in (rows = schedule steps, or samples)."""
+        w, b = self.time_emb_proj.dev_f32()
+        cb = self.conv1.bias.detach().float().to(DEV)
+        self.tbias = ops.linear_f32(silu_emb, w, b + cb)
+
+    def run(self, x, x2=None, step=None, sample_bias=None):
+        """x (+x2: virtual concat) NHWC bf16.  step: row of the time table; sample_bias: [N,cout] per-image rows."""
+        h = self.norm1.run(x, silu=True, x2=x2)
+        bias = None
+        if self.time_emb_proj is not None:
+            bias = sample_bias if sample_bias is not None else self.tbias[step]
+        h = ops.conv(h, self.conv1.packed(), bias=bias)
+        h = self.norm2.run(h, silu=True)
+        if self.conv_shortcut is not None:
+            sc = ops.conv(x, self.conv_shortcut.packed(), x2=x2)
+        else:
+            sc = x
+        return ops.conv(h, self.conv2.packed(), residual=sc)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, c, padding):
+        super().__init__()
+        self.padding = padding
+        self.conv = Conv2d(c, c, 3, stride=2, padding=padding)
+
+    def run(self, x):
+        n, h, w, _ = x.shape
+        if self.padding == 0:          # VAE encoder: zero pad right/bottom by one, then stride-2 VALID conv
+            return ops.conv(x, self.conv.packed(), stride=2, pad=(0, 0), out_hw=(h // 2, w // 2))
+        return ops.conv(x, self.conv.packed(), stride=2, pad=(1, 1))
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = Conv2d(c, c, 3, padding=1)
+
+    def run(self, x):
+        return ops.conv(x, self.conv.packed(), upsample=True)      # nearest-2x gather fused into the loader
+
+
+# ----------------------------------------------------------------------------------------------- attention
+class _ToOut(nn.ModuleList):
+    def __init__(self, c):
+        super().__init__([Linear(c, c), nn.Identity()])
+
+
+def _fused_qkv(mod, names):
+    if ("cache", "qkv") not in mod.__dict__:
+        ws = [getattr(mod, n).weight for n in names]
+        bs = [getattr(mod, n).bias for n in names]
+        w = torch.cat([t.detach().float() for t in ws], 0)
+        b = None if bs[0] is None else torch.cat([t.detach().float() for t in bs], 0)
+        mod.__dict__[("cache", "qkv")] = ops.pack_conv(w, b, DEV)
+    return mod.__dict__[("cache", "qkv")]
+
+
+def self_attention(mod, h, heads, residual):
+    """h: [B,T,C] bf16 (already normalised).  One fused QKV GEMM (V written transposed), flash attention,
+    output projection with the residual in its epilogue."""
+    b, t, c = h.shape
+    d = c // heads
+    ldvt = ops.round_up(t, 8)
+    vt = torch.zeros((b, c, ldvt), dtype=ops.BF16, device=h.device) if ldvt != t else \
+        torch.empty((b, c, ldvt), dtype=ops.BF16, device=h.device)
+    qk = ops.linear(h, _fused_qkv(mod, ("to_q", "to_k", "to_v")), yt=vt, n_split=2 * c, t_rows=t)   # [B,T,3C] (V cols unused)
+    if d in (64, 128):
+        o = ops.attention(qk, qk[:, :, c:], vt, heads, d, t, t, 1.0 / math.sqrt(d), ldq=3 * c, ldk=3 * c,
+                          bs_q=t * 3 * c, bs_k=t * 3 * c, bs_vt=c * ldvt, batch=b)
+    else:
+        o = attention_gemm(qk[:, :, :c], qk[:, :, c:2 * c], vt, heads, d, t)
+    return ops.linear(o, mod.to_out[0].packed(), residual=residual)
+
+
+def attention_gemm(q, k, vt, heads, d, t):
+    """Large-head-dim attention (VAE mid block: 1 head x 512) as S = QK^T (fp32) -> row softmax -> P V."""
+    b = q.shape[0]
+    outs = []
+    for hh in range(heads):
+        s = ops.bmm_nt(q[:, :, hh * d:(hh + 1) * d], k[:, :, hh * d:(hh + 1) * d], out_f32=True, out_scale=1.0 / math.sqrt(d))
+        p = ops.softmax_rows(s, ldp=vt.shape[-1])
+        outs.append(ops.bmm_nt(p, vt[:, hh * d:(hh + 1) * d, :]))
+    return outs[0] if heads == 1 else torch.cat(outs, -1)
+
+
+class AttentionBlock(nn.Module):
+    """Legacy spatial self-attention (VAE mid block; Controller AttnDownBlock2D / UNetMidBlock2D)."""
+
+    def __init__(self, c, head_dim, groups=32, eps=1e-5):
+        super().__init__()
+        self.heads = c // head_dim
+        self.group_norm = GroupNorm(groups, c, eps=eps)
+        self.to_q, self.to_k, self.to_v = Linear(c, c), Linear(c, c), Linear(c, c)
+        self.to_out = _ToOut(c)
+
+    def run(self, x):
+        n, hh, ww, c = x.shape
+        h = self.group_norm.run(x).view(n, hh * ww, c)
+        return self_attention(self, h, self.heads, x.view(n, hh * ww, c)).view(n, hh, ww, c)
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, c, heads, kv_dim=None):
+        super().__init__()
+        self.heads = heads
+        kv_dim = kv_dim or c
+        self.to_q = Linear(c, c, bias=False)
+        self.to_k = Linear(kv_dim, c, bias=False)
+        self.to_v = Linear(kv_dim, c, bias=False)
+        self.to_out = _ToOut(c)
+
+    def context_kv(self, ctx: torch.Tensor):
+        """K [Tk,C] and V^T [C,ldvt] of the (constant) context, computed once (base_model.py:23-27,221)."""
+        key = ("cache", "ctx")
+        if key not in self.__dict__:
+            tk = ctx.shape[1]
+            c = self.to_q.out_features
+            kv = _fused_qkv(self, ("to_k", "to_v"))
+            vt = torch.zeros((1, c, ops.round_up(tk, 8)), dtype=ops.BF16, device=DEV)
+            k = ops.linear(ctx, kv, yt=vt, n_split=c, t_rows=tk)      # [1,Tk,2C]; K = first C columns
+            self.__dict__[key] = (k, vt, tk)
+        return self.__dict__[key]
+
+    def run_cross(self, h, ctx, residual):
+        b, t, c = h.shape
+        d = c // self.heads
+        k, vt, tk = self.context_kv(ctx)
+        q = ops.linear(h, self.to_q.packed())
+        o = ops.attention(q, k, vt, self.heads, d, t, tk, 1.0 / math.sqrt(d), ldq=c, ldk=2 * c, bs_q=t * c, bs_k=0,
+                          bs_vt=0, batch=b)
+        return ops.linear(o, self.to_out[0].packed(), residual=residual)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, c, inner):
+        super().__init__()
+        self.proj = Linear(c, inner * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(c, 4 * c), nn.Identity(), Linear(4 * c, c)])
+
+    def run(self, h, residual):
+        a = ops.linear(h, self.net[0].proj.packed(pair=True), act=UR_ACT_GEGLU)     # a * gelu(g) in the epilogue
+        return ops.linear(a, self.net[2].packed(), residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, c, heads, cross_dim):
+        super().__init__()
+        self.norm1, self.attn1 = LayerNorm(c), CrossAttention(c, heads)
+        self.norm2, self.attn2 = LayerNorm(c), CrossAttention(c, heads, cross_dim)
+        self.norm3, self.ff = LayerNorm(c), FeedForward(c)
+
+    def run(self, h, ctx):
+        h = self_attention(self.attn1, self.norm1.run(h), self.attn1.heads, h)
+        h = self.attn2.run_cross(self.norm2.run(h), ctx, h)
+        return self.ff.run(self.norm3.run(h), h)
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, c, heads, cross_dim, groups=32):
+        super().__init__()
+        self.norm = GroupNorm(groups, c, eps=1e-6)
+        self.proj_in = Linear(c, c)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(c, heads, cross_dim)])
+        self.proj_out = Linear(c, c)
+
+    def run(self, x, ctx):
+        n, hh, ww, c = x.shape
+        h = ops.linear(self.norm.run(x).view(n, hh * ww, c), self.proj_in.packed())
+        h = self.transformer_blocks[0].run(h, ctx)
+        return ops.linear(h, self.proj_out.packed(), residual=x.view(n, hh * ww, c)).view(n, hh, ww, c)
+
+
+# ----------------------------------------------------------------------------------------------- blocks
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb, attn=None, heads=None, head_dim=None, cross_dim=None,
+                 add_downsample=True, layers=2, groups=32, eps=1e-5):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups, eps) for i in range(layers)])
+        self.attn_kind = attn
+        if attn == "cross":
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups) for _ in range(layers)])
+        elif attn == "self":
+            self.attentions = nn.ModuleList([AttentionBlock(cout, head_dim, groups, eps) for _ in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout, 1)]) if add_downsample else None
+
+
+class MidBlock(nn.Module):
+    def __init__(self, c, temb, attn, heads=None, head_dim=None, cross_dim=None, groups=32, eps=1e-5):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, groups, eps) for _ in range(2)])
+        self.attn_kind = attn
+        if attn == "cross":
+            self.attentions = nn.ModuleList([Transformer2DModel(c, heads, cross_dim, groups)])
+        else:
+            self.attentions = nn.ModuleList([AttentionBlock(c, head_dim, groups, eps)])
+
+    def run(self, h, step=None, ctx=None, sample_bias=None):
+        sb = sample_bias or (None, None)
+        h = self.resnets[0].run(h, step=step, sample_bias=sb[0])
+        h = self.attentions[0].run(h, ctx) if self.attn_kind == "cross" else self.attentions[0].run(h)
+        return self.resnets[1].run(h, step=step, sample_bias=sb[1])
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, cout, prev, temb, attn=None, heads=None, cross_dim=None,
+                 add_upsample=True, layers=3, groups=32, eps=1e-5):
+        super().__init__()
+        res = []
+        for i in range(layers):
+            skip = cin if i == layers - 1 else cout
+            rin = prev if i == 0 else cout
+            res.append(ResnetBlock2D(rin + skip, cout, temb, groups, eps))
+        self.resnets = nn.ModuleList(res)
+        self.attn_kind = attn
+        if attn == "cross":
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups) for _ in range(layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_upsample else None
+
+
+class UNet2DConditionModel(nn.Module):
+    """SD-2.1 UNet parameter tree (HF names).  Walked by ControlledUNet, as base_model.py:94-209 does."""
+
+    def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+                 heads=(5, 10, 20, 20), cross_dim=1024, groups=32, layers=2):
+        super().__init__()
+        ch = list(block_out_channels)
+        self.time_proj_dim = ch[0]
+        temb = ch[0] * 4
+        self.time_embedding = TimestepEmbedding(ch[0], temb)
+        self.conv_in = Conv2d(in_channels, ch[0], 3, padding=1)
+        nb = len(ch)
+        self.down_blocks = nn.ModuleList()
+        out = ch[0]
+        for i in range(nb):
+            cin, out = out, ch[i]
+            last = i == nb - 1
+            self.down_blocks.append(DownBlock(cin, out, temb, attn=None if last else "cross", heads=heads[i],
+                                              cross_dim=cross_dim, add_downsample=not last, layers=layers, groups=groups))
+        self.mid_block = MidBlock(ch[-1], temb, "cross", heads=heads[-1], cross_dim=cross_dim, groups=groups)
+        rev, rheads = ch[::-1], list(heads)[::-1]
+        self.up_blocks = nn.ModuleList()
+        out = rev[0]
+        for i in range(nb):
+            prev, out = out, rev[i]
+            cin = rev[min(i + 1, nb - 1)]
+            self.up_blocks.append(UpBlock(cin, out, prev, temb, attn=None if i == 0 else "cross", heads=rheads[i],
+                                          cross_dim=cross_dim, add_upsample=i < nb - 1, layers=layers + 1, groups=groups))
+        self.conv_norm_out = GroupNorm(groups, ch[0], eps=1e-5)
+        self.conv_out = Conv2d(ch[0], out_channels, 3, padding=1)
+
+
+# ----------------------------------------------------------------------------------------------- VAE
+class EncDownBlock(nn.Module):
+    def __init__(self, cin, cout, add_downsample, groups, layers=2):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(cin if i == 0 else cout, cout, None, groups, 1e-6) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout, 0)]) if add_downsample else None
+
+    def run(self, h):
+        for r in self.resnets:
+            h = r.run(h)
+        return self.downsamplers[0].run(h) if self.downsamplers is not None else h
+
+
+class DecUpBlock(nn.Module):
+    def __init__(self, cin, cout, add_upsample, groups, layers=3):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(cin if i == 0 else cout, cout, None, groups, 1e-6) for i in range(layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_upsample else None
+
+    def run(self, h):
+        for r in self.resnets:
+            h = r.run(h)
+        return self.upsamplers[0].run(h) if self.upsamplers is not None else h
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels, latent_channels, ch, groups):
+        super().__init__()
+        self.conv_in = Conv2d(in_channels, ch[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        out = ch[0]
+        for i in range(len(ch)):
+            cin, out = out, ch[i]
+            self.down_blocks.append(EncDownBlock(cin, out, i < len(ch) - 1, groups))
+        self.mid_block = MidBlock(ch[-1], None, "self", head_dim=ch[-1], groups=groups, eps=1e-6)
+        self.conv_norm_out = GroupNorm(groups, ch[-1], eps=1e-6)
+        self.conv_out = Conv2d(ch[-1], 2 * latent_channels, 3, padding=1)
+
+
+class Decoder(nn.Module):
+    def __init__(self, out_channels, latent_channels, ch, groups):
+        super().__init__()
+        rev = list(ch)[::-1]
+        self.conv_in = Conv2d(latent_channels, rev[0], 3, padding=1)
+        self.mid_block = MidBlock(rev[0], None, "self", head_dim=rev[0], groups=groups, eps=1e-6)
+        self.up_blocks = nn.ModuleList()
+        out = rev[0]
+        for i in range(len(rev)):
+            prev, out = out, rev[i]
+            self.up_blocks.append(DecUpBlock(prev, out, i < len(rev) - 1, groups))
+        self.conv_norm_out = GroupNorm(groups, rev[-1], eps=1e-6)
+        self.conv_out = Conv2d(rev[-1], out_channels, 3, padding=1)
+
+
+class _VaeConfig:
+    scaling_factor = 0.18215
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, in_channels=3, out_channels=3, latent_channels=4,
+                 block_out_channels=(128, 256, 512, 512), groups=32):
+        super().__init__()
+        self.latent_channels = latent_channels
+        self.config = _VaeConfig()
+        self.encoder = Encoder(in_channels, latent_channels, block_out_channels, groups)
+        self.decoder = Decoder(out_channels, latent_channels, block_out_channels, groups)
+        self.quant_conv = Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+        self.post_quant_conv = Conv2d(latent_channels, latent_channels, 1)

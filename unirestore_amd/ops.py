@@ -63,7 +63,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=F
     cout, cin_g, kh, kw = w.shape
     assert kh == kw and kh in (1, 3)
     cin_p = cin_pad or round_up(cin_g, 8)
-    cout_p = round_up(cout, 4)
+    cout_p = round_up(cout, 8)           # outputs feed the next conv: keep C % 8 == 0 (padded rows are zero)
     if groups > 1:
         assert cin_g % 8 == 0 and (cout // groups) % 4 == 0
     wp = torch.zeros(cout_p, kh, kw, cin_p, dtype=torch.float32)
@@ -85,7 +85,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=F
 
 
 # ------------------------------------------------------------------------------------------------ conv / gemm
-def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, act=UR_ACT_NONE, stride=1, pad=None,
+def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, act=UR_ACT_NONE, stride=1, pad=None,
          out_hw=None, upsample=False, out_f32=False, out_scale=1.0, out=None, yt=None, n_split=0, t_rows=0,
          colsum=None, colsum_scale=1.0):
     """x: [N,H,W,C1] bf16 (x2 optional [N,H,W,C2], virtual concat).  Returns [N,OH,OW,cout_out]."""
@@ -105,7 +105,10 @@ def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, act=UR_ACT_
     if out is None and colsum is None:
         out = torch.empty((n, oh, ow, co_total), dtype=torch.float32 if out_f32 else BF16, device=x.device)
     d = ConvDesc()
-    d.x, d.x2, d.w, d.bias = _ptr(x), _ptr(x2), _ptr(pc.w), _ptr(pc.bias)
+    bias_t = pc.bias if bias is None else bias          # override: per-step (time-embedding) or per-image bias rows
+    d.x, d.x2, d.w, d.bias = _ptr(x), _ptr(x2), _ptr(pc.w), _ptr(bias_t)
+    if bias is not None and bias.dim() == 2 and bias.shape[0] > 1:
+        d.bias_img_stride = bias.shape[1]
     d.residual, d.y, d.yt, d.colsum = _ptr(residual), _ptr(out), _ptr(yt), _ptr(colsum)
     ws = workspace(x.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -159,15 +162,17 @@ def bmm_nt(a: torch.Tensor, bmat: torch.Tensor, *, out_f32=False, out_scale=1.0)
 
 
 # ------------------------------------------------------------------------------------------------ norms
-def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu=False, out=None):
-    """x: [N,H,W,C] (or [N,HW,C]) bf16.  gamma/beta fp32 [C] or None (InstanceNorm when groups == C)."""
+def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu=False, x2=None):
+    """x: [N,H,W,C1] bf16 (+ optional x2 [N,H,W,C2], normalised as one concatenated tensor) -> [N,H,W,C1+C2].
+    gamma/beta fp32 [C] or None (InstanceNorm when groups == C)."""
     assert x.dtype == BF16 and x.is_contiguous()
-    n, c = x.shape[0], x.shape[-1]
-    hw = x.numel() // (n * c)
-    out = torch.empty_like(x) if out is None else out
-    ws = _gn_ws(x.device, lib.ur_groupnorm_ws_bytes(n, c))
-    check(lib.ur_groupnorm_nhwc(x.data_ptr(), out.data_ptr(), _ptr(gamma), _ptr(beta), n, hw, c, groups, eps, int(silu),
-                                ws.data_ptr(), _stream()))
+    n, c1 = x.shape[0], x.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    hw = x.numel() // (n * c1)
+    out = torch.empty((*x.shape[:-1], c1 + c2), dtype=BF16, device=x.device)
+    ws = _gn_ws(x.device, lib.ur_groupnorm_ws_bytes(n, c1 + c2))
+    check(lib.ur_groupnorm_nhwc(x.data_ptr(), _ptr(x2), out.data_ptr(), _ptr(gamma), _ptr(beta), n, hw, c1, c2, groups, eps,
+                                int(silu), ws.data_ptr(), _stream()))
     return out
 
 
