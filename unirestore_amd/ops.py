@@ -56,8 +56,9 @@ class PackedConv:
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=False, groups=1, cin_pad=None) -> PackedConv:
-    """weight: [Cout, Cin/groups, k, k] (nn.Conv2d) or [N, K] (nn.Linear), fp32 master on any device."""
-    w = weight.detach().to(torch.float32)
+    """weight: [Cout, Cin/groups, k, k] (nn.Conv2d) or [N, K] (nn.Linear), fp32 master on any device.
+    The repack (OIHW -> O,kh,kw,I; zero padding; a|g interleave; bf16 cast) runs on `dev` with torch copies."""
+    w = weight.detach().to(dev, torch.float32)
     if w.dim() == 2:
         w = w[:, :, None, None]
     cout, cin_g, kh, kw = w.shape
@@ -66,22 +67,25 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=F
     cout_p = round_up(cout, 8)           # outputs feed the next conv: keep C % 8 == 0 (padded rows are zero)
     if groups > 1:
         assert cin_g % 8 == 0 and (cout // groups) % 4 == 0
-    wp = torch.zeros(cout_p, kh, kw, cin_p, dtype=torch.float32)
-    wp[:cout, :, :, :cin_g] = w.permute(0, 2, 3, 1).cpu()
+    if cin_p == cin_g and cout_p == cout:
+        wp = w.permute(0, 2, 3, 1).contiguous()
+    else:
+        wp = torch.zeros(cout_p, kh, kw, cin_p, dtype=torch.float32, device=dev)
+        wp[:cout, :, :, :cin_g] = w.permute(0, 2, 3, 1)
     b = None
     if bias is not None:
-        b = torch.zeros(cout_p, dtype=torch.float32)
-        b[:cout] = bias.detach().float().cpu()
+        b = torch.zeros(cout_p, dtype=torch.float32, device=dev)
+        b[:cout] = bias.detach().to(dev, torch.float32)
     cout_out = cout_p
     if pair:
         half = cout // 2
         assert cout % 2 == 0 and half % 32 == 0, "pair activations need (Cout/2) % 32 == 0"
-        idx = torch.arange(cout).view(2, half // 32, 32).permute(1, 0, 2).reshape(-1)   # [blk][a|g][32]
+        idx = torch.arange(cout, device=dev).view(2, half // 32, 32).permute(1, 0, 2).reshape(-1)   # [blk][a|g][32]
         wp = wp[idx]
         b = b[idx] if b is not None else None
         cout_out = half
-    return PackedConv(wp.reshape(cout_p, kh * kw * cin_p).to(dev, BF16).contiguous(),
-                      None if b is None else b.to(dev).contiguous(), cin_p, cout_p, cout_out, kh, groups, pair)
+    return PackedConv(wp.reshape(cout_p, kh * kw * cin_p).to(BF16).contiguous(),
+                      None if b is None else b.contiguous(), cin_p, cout_p, cout_out, kh, groups, pair)
 
 
 # ------------------------------------------------------------------------------------------------ conv / gemm
