@@ -86,13 +86,14 @@ int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream);
  * GroupNorm over NHWC (+ optional SiLU).  G == C with gamma=beta=NULL gives InstanceNorm2d.
  * Replaces: nn.GroupNorm(32,C)+SiLU in every ResnetBlock2D / conv_norm_out, Transformer2D / Attention
  *   pre-norms, AdaNAFV2.group_norm (cfrm.py:19), nn.InstanceNorm2d (taskeditor.py:31,40,49).
- * ws: fp32 scratch of ur_groupnorm_ws_bytes(N, C) bytes.
+ * ws: scratch of ur_groupnorm_ws_bytes(N, C) bytes that must be ZERO on first use (it is left zero by every call).
  */
-size_t ur_groupnorm_ws_bytes(int N, int C);
+size_t ur_groupnorm_ws_bytes(int N, int C); /* fp64 channel sums: zero on first use, left zero by every call */
+size_t ur_groupnorm_ab_bytes(int N, int C); /* fp32 per-(image, channel) affine table: plain scratch */
 /* x2/C2 (optional): second source tensor, virtually concatenated after x's C1 channels (UNet up path:
  * GroupNorm over torch.cat([sample, skip]), base_model.py:189,197); y is [N,HW,C1+C2]. */
 int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int N, int HW,
-                      int C1, int C2, int G, float eps, int silu, void* ws, ur_stream_t stream);
+                      int C1, int C2, int G, float eps, int silu, void* ws, float* ab, ur_stream_t stream);
 /* LayerNorm over the last dim of [rows, C] bf16 (nn.LayerNorm in BasicTransformerBlock; timm LayerNorm2d
  * in NAFBlock, nafnet_arch.py:97-98, which is LayerNorm-over-C in NHWC). */
 int ur_layernorm_rows(const void* x, void* y, const float* gamma, const float* beta, long long rows, int C,

@@ -40,7 +40,8 @@ SIGNATURES = {
     "ur_last_error": (C.c_char_p, []),
     "ur_conv2d_nhwc": (_I, [C.POINTER(ConvDesc), _P]),
     "ur_groupnorm_ws_bytes": (_SZ, [_I, _I]),
-    "ur_groupnorm_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "ur_groupnorm_ab_bytes": (_SZ, [_I, _I]),
+    "ur_groupnorm_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P]),
     "ur_layernorm_rows": (_I, [_P, _P, _P, _P, _LL, _I, _F, _P]),
     "ur_softmax_rows_f32": (_I, [_P, _P, _LL, _I, _I, _P]),
     "ur_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL, _F, _P]),

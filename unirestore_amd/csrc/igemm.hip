@@ -12,7 +12,12 @@
 //     ds_write_b128 staging pattern and the ds_read_b128 fragment pattern of 32-row MFMA operands.
 //   * zero padding, stride, nearest-2x upsample and channel concat are address arithmetic in the loader.
 //   * block id -> tile map is XCD-aware (blocks that share an activation tile land on one XCD's L2).
+#include <cstdlib>
+
 #include "common.h"
+
+// 128 B of zeros: the global source of every padded / out-of-range 16-byte piece of the LDS-DMA loader.
+__device__ uint4 g_zero_page[8];
 
 namespace {
 
@@ -25,11 +30,21 @@ struct ConvK {
   int M, Ktot, nk, tiles_m, tiles_n, splitk, nk_per_split, nbatch;
   long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r, bias_img;
   size_t ws_bytes_;
+  int dbg;
 };
 
 __device__ __forceinline__ bool is_pair_act(int act) { return act == UR_ACT_GEGLU || act == UR_ACT_GATE; }
 
 // Final stage for 4 consecutive output channels [co, co+4) of pixel row m (values already activated/scaled).
+__device__ __forceinline__ void epi_residual(const ConvK& p, int gb, int m, int co, float v[4]) {
+  if (p.res) {
+    const uint16_t* r = p.res + gb * p.bs_r + (long long)m * p.ldr + co;
+    uint2 rv = *reinterpret_cast<const uint2*>(r);
+    v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+    v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+  }
+}
+
 __device__ __forceinline__ void epi_store(const ConvK& p, int gb, int m, int co, float v[4]) {
   if (p.res) {
     const uint16_t* r = p.res + gb * p.bs_r + (long long)m * p.ldr + co;
@@ -81,6 +96,183 @@ __device__ __forceinline__ int epi_act(const ConvK& p, int gb, int m, int co_in,
 #pragma unroll
   for (int e = 0; e < 4; ++e) a[e] *= p.out_scale;
   return co;
+}
+
+// Shared epilogue: acc[FN][FM] 32x32 fragments of the wave tile at (m0 + wm*WTM, n0 + wn*WTN).
+// Row-contiguous tile <-> global copy with 16-byte accesses; NC (tile columns) is a compile-time constant so the
+// (row, chunk) split is a multiply-shift, and LDS rows (stride SROW, 8-byte aligned) are touched with ds_*_b64.
+// Loads are issued in batches of U before any is consumed (latency paid once per batch, not once per chunk).
+template <int BM, int NC, int NT, int SROW, bool LOAD>
+__device__ __forceinline__ void tile_copy(uint16_t* g, long long ld, unsigned char* smem, int m0, int M, int c0, int cmax) {
+  constexpr int Q = NC / 8;                               // 16-byte chunks per row
+  constexpr int TOT = BM * Q, U = 5;
+  for (int i0 = threadIdx.x; i0 < TOT; i0 += NT * U) {
+    uint4 v[U];
+    uint16_t* gp[U];
+    uint2* lp[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * NT;
+      const int r = i / Q, c = (i - r * Q) * 8;
+      ok[u] = i < TOT && m0 + r < M && c < cmax;
+      gp[u] = g + (long long)(m0 + (ok[u] ? r : 0)) * ld + c0 + (ok[u] ? c : 0);
+      lp[u] = reinterpret_cast<uint2*>(smem + (ok[u] ? r * SROW + c * 2 : 0));
+      if (LOAD) v[u] = *reinterpret_cast<const uint4*>(gp[u]);
+      else { const uint2 a = lp[u][0], b = lp[u][1]; v[u] = make_uint4(a.x, a.y, b.x, b.y); }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      if (LOAD) { lp[u][0] = make_uint2(v[u].x, v[u].y); lp[u][1] = make_uint2(v[u].z, v[u].w); }
+      else *reinterpret_cast<uint4*>(gp[u]) = v[u];
+    }
+  }
+}
+
+// Generic (unstaged) epilogue: fp32 outputs, transposed outputs, fused column sums, odd leading dimensions.
+template <int FM, int FN, int WTM, int WTN>
+__device__ __forceinline__ void igemm_epilogue_direct(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn,
+                                                      int lane, int gb) {
+  const int fhalf = lane >> 5, mrow = lane & 31;
+  const bool pair = is_pair_act(p.act);
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    if (pair && (a & 1)) continue;
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      int m = m0 + wm * WTM + b * 32 + mrow;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        int co_in = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
+        bool ok = m < p.M && co_in < p.Cout;
+        float v[4], g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][rg * 4 + e];
+        if (pair) {
+          constexpr int a1 = (FN > 1) ? 1 : 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = acc[(a + a1) % FN][b][rg * 4 + e];
+        }
+        int co = co_in;
+        if (ok) co = epi_act(p, gb, m, co_in, v, g);
+        if (p.colsum) {  // per-image column sums of the activated output (all 32 lanes share co)
+          int mclamp = min(m, p.M - 1);
+          int img = mclamp / p.OHW;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float s = ok ? v[e] : 0.f;
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+            if (mrow == 0 && co_in < p.Cout) {
+              int cw = pair ? p.Cout / 2 : p.Cout;   // colsum is [N][nbatch*cw]: batch index = channel group
+              atomicAdd(p.colsum + ((long long)img * p.nbatch + gb) * cw + co + e, s * p.colsum_scale);
+            }
+          }
+        }
+        if (ok) epi_store(p, gb, m, co, v);
+      }
+    }
+  }
+}
+
+// Shared epilogue.  The common case (bf16 output) is STAGED: bias row and residual tile are brought into LDS with
+// coalesced 16-byte loads (the K ring is free by then), the fragment pass is branch-free LDS-only math that
+// overwrites the residual tile in place with the result, and the tile leaves with 16-byte row-contiguous stores.
+// (The MFMA fragment layout would otherwise touch 16-byte runs per pixel per instruction, and a global bias load
+// inside each quad's branch serialised ~20 memory latencies per lane.)
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT>
+__device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
+                                               int gb, int sz, unsigned char* smem) {
+  const int fhalf = lane >> 5, mrow = lane & 31;
+  if (p.splitk > 1) {
+    float* ws = p.ws + ((long long)(sz * p.nbatch + gb) * p.M) * p.Cout;
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        int m = m0 + wm * WTM + b * 32 + mrow;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
+          if (m < p.M && co < p.Cout)
+            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =
+                make_float4(acc[a][b][rg * 4], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
+        }
+      }
+    return;
+  }
+  const bool pair = is_pair_act(p.act);
+  constexpr int SROW = BN * 2 + 8;                       // staged row stride in bytes (+8 spreads the ds_write_b64 banks)
+  const bool staged = p.y && !p.out_f32 && !p.colsum && !p.bias_img && ((p.ldy | p.bs_y) & 7) == 0 &&
+                      (!p.res || ((p.ldr | p.bs_r) & 7) == 0) && BN >= 32;
+  if (!staged) {
+    igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
+    return;
+  }
+  const int c0 = pair ? (n0 >> 1) : n0;                  // first output column of this tile
+  const int ncols = pair ? BN / 2 : BN;
+  const int cmax = min(p.yt ? p.n_split : (pair ? p.Cout / 2 : p.Cout), c0 + ncols) - c0;     // valid output columns here
+  float* sbias = reinterpret_cast<float*>(smem + BM * SROW);                                   // BN floats (GEMM-N order)
+  for (int i = threadIdx.x; i < BN; i += NT)
+    sbias[i] = (p.bias && n0 + i < p.Cout) ? p.bias[gb * p.bs_bias + n0 + i] : 0.f;
+  if (p.res) {                                            // residual tile -> LDS, coalesced
+    uint16_t* rb = const_cast<uint16_t*>(p.res) + gb * p.bs_r;
+    if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, true>(rb, p.ldr, smem, m0, p.M, c0, cmax);
+    else tile_copy<BM, BN, NT, SROW, true>(rb, p.ldr, smem, m0, p.M, c0, cmax);
+  }
+  __syncthreads();
+  const bool has_res = p.res != nullptr;
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    if (pair && (a & 1)) continue;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int ln = wn * WTN + a * 32 + rg * 8 + fhalf * 4;          // column inside the tile (GEMM-N space)
+      const int co_in = n0 + ln;
+      const float4 bv = *reinterpret_cast<const float4*>(sbias + ln);
+      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pair) gv = *reinterpret_cast<const float4*>(sbias + ln + 32);
+      const int lco = pair ? ((ln >> 6) * 32 + (ln & 31)) : ln;        // column inside the OUTPUT tile
+      const int co = c0 + lco;
+      const bool col_ok = co_in < p.Cout;
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        const int lm = wm * WTM + b * 32 + mrow;
+        float v[4] = {acc[a][b][rg * 4] + bv.x, acc[a][b][rg * 4 + 1] + bv.y, acc[a][b][rg * 4 + 2] + bv.z,
+                      acc[a][b][rg * 4 + 3] + bv.w};
+        if (pair) {
+          constexpr int a1 = (FN > 1) ? 1 : 0;
+          const float g0 = acc[(a + a1) % FN][b][rg * 4] + gv.x, g1 = acc[(a + a1) % FN][b][rg * 4 + 1] + gv.y;
+          const float g2 = acc[(a + a1) % FN][b][rg * 4 + 2] + gv.z, g3 = acc[(a + a1) % FN][b][rg * 4 + 3] + gv.w;
+          if (p.act == UR_ACT_GEGLU) { v[0] *= gelu_f(g0); v[1] *= gelu_f(g1); v[2] *= gelu_f(g2); v[3] *= gelu_f(g3); }
+          else { v[0] *= g0; v[1] *= g1; v[2] *= g2; v[3] *= g3; }
+        } else if (p.act != UR_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+        const bool ok = col_ok && m0 + lm < p.M;
+        if (p.yt && co >= p.n_split) {                                   // transposed columns (V^T) go out directly
+          if (ok) epi_store(p, gb, m0 + lm, co, v);
+          continue;
+        }
+        uint2* sp = reinterpret_cast<uint2*>(smem + lm * SROW + lco * 2);
+        if (has_res) {
+          const uint2 rv = *sp;
+          v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+          v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+        }
+        if (ok) *sp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+    }
+  }
+  if (p.dbg & 16) return;
+  __syncthreads();
+  uint16_t* yb = reinterpret_cast<uint16_t*>(p.y) + gb * p.bs_y;
+  if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, false>(yb, p.ldy, smem, m0, p.M, c0, cmax);
+  else tile_copy<BM, BN, NT, SROW, false>(yb, p.ldy, smem, m0, p.M, c0, cmax);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -231,64 +423,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     }
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------------------
-  const int mrow = lane & 31;
-  if (p.splitk > 1) {
-    float* ws = p.ws + ((long long)(sz * p.nbatch + gb) * p.M) * p.Cout;
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        int m = m0 + wm * WTM + b * 32 + mrow;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
-          if (m < p.M && co < p.Cout)
-            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =
-                make_float4(acc[a][b][rg * 4], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
-        }
-      }
-    return;
-  }
-  const bool pair = is_pair_act(p.act);
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    if (pair && (a & 1)) continue;
-#pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      int m = m0 + wm * WTM + b * 32 + mrow;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        int co_in = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
-        bool ok = m < p.M && co_in < p.Cout;
-        float v[4], g[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][rg * 4 + e];
-        if (pair) {
-          constexpr int a1 = (FN > 1) ? 1 : 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = acc[(a + a1) % FN][b][rg * 4 + e];
-        }
-        int co = co_in;
-        if (ok) co = epi_act(p, gb, m, co_in, v, g);
-        if (p.colsum) {  // per-image column sums of the activated output (all 32 lanes share co)
-          int mclamp = min(m, p.M - 1);
-          int img = mclamp / p.OHW;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float s = ok ? v[e] : 0.f;
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-            s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
-            if (mrow == 0 && co_in < p.Cout) {
-              int cw = pair ? p.Cout / 2 : p.Cout;   // colsum is [N][nbatch*cw]: batch index = channel group
-              atomicAdd(p.colsum + ((long long)img * p.nbatch + gb) * cw + co + e, s * p.colsum_scale);
-            }
-          }
-        }
-        if (ok) epi_store(p, gb, m, co, v);
-      }
-    }
-  }
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, 256>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p) {
@@ -355,6 +490,199 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
+
+// =====================================================================================================================
+// v2 main loop: LDS-DMA (global_load_lds_dwordx4) into an NST-deep ring, counted vmcnt, one raw s_barrier per K tile.
+//   * each wave-instruction lands 1 KiB = 8 rows x 128 B lane-linearly; the XOR swizzle therefore lives on the
+//     SOURCE address (lane's physical slot ps reads logical chunk ps ^ ((row>>1)&7) of its row) - same 128-B line,
+//     so coalescing is unchanged and the fragment reads stay conflict-free;
+//   * padded / out-of-range pieces read a 16-byte zero page instead of being predicated (every wave issues the
+//     same number of DMA ops per tile, so one immediate vmcnt(N) is right for all waves);
+//   * no VGPR staging: the ring is NST-1 tiles ahead of the MFMAs (HBM/L2 latency hidden across barriers).
+template <int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) {
+  constexpr int NT = WM * WN * 64, RPP = NT / 8;                  // threads; tile rows covered by one loader pass
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
+  constexpr int XP = BM / RPP, WP = (BN + RPP - 1) / RPP, NLD = XP + WP;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(BM % RPP == 0 && WTM % 32 == 0 && WTN % 32 == 0 && RPP % 16 == 0, "tile/wave shape");
+  static_assert(BN % RPP == 0 || (BN % RPP) * 2 == RPP, "partial W pass must be exactly half a pass");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid % WM, wn = wid / WM;
+  const int gb = blockIdx.y, sz = blockIdx.z;
+  int id = blockIdx.x;
+  {
+    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
+  const uint16_t* __restrict__ X2 = p.x2 ? p.x2 + gb * p.bs_x2 : nullptr;
+  const uint16_t* __restrict__ Wt = p.w + gb * p.bs_w;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+
+  const int lrow = tid >> 3;                                       // row inside a loader pass
+  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);                 // logical 16-B K chunk this lane fetches
+  int ih0[XP], iw0[XP], nb[XP];
+  bool xok[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    int m = m0 + i * RPP + lrow;
+    xok[i] = m < p.M;
+    int mm = xok[i] ? m : 0;
+    int n = mm / p.OHW, rem = mm - n * p.OHW;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+    ih0[i] = oh * p.stride - p.pad_t;
+    iw0[i] = ow * p.stride - p.pad_l;
+    nb[i] = n * p.H;
+  }
+  long long woff[WP];
+  bool wok[WP];
+  int wrow_lds[WP];
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    int lr = j * RPP + lrow;
+    if (lr >= BN) lr -= RPP / 2;          // half pass: the upper waves re-fetch the lower half (identical bytes)
+    wrow_lds[j] = lr;
+    int row = n0 + lr;
+    wok[j] = row < p.Cout;
+    woff[j] = (long long)(wok[j] ? row : 0) * p.ldw;
+  }
+  const int Hlim = p.ups ? p.H * 2 : p.H, Wlim = p.ups ? p.W * 2 : p.W;
+
+  const int kt_begin = sz * p.nk_per_split;
+  const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
+  int kcur = kt_begin * 64 + chunk * 8;
+  int tap = kcur / p.Cin, cch = kcur - tap * p.Cin;
+
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_tile = [&](int stage) {
+    unsigned char* xs = smem + stage * STAGE;
+    unsigned char* wsm = xs + BM * 128;
+    const bool kval = kcur < p.Ktot;
+    const int dy = (p.KW == 1) ? 0 : (tap * 11) >> 5;
+    const int dx = tap - dy * p.KW;
+    const uint16_t* src = X1;
+    int ld = p.ldx, cc = cch;
+    if (cch >= p.C1) { src = X2; ld = p.ldx2; cc = cch - p.C1; }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      int ih = ih0[i] + dy, iw = iw0[i] + dx;
+      bool v = kval && xok[i] && (unsigned)ih < (unsigned)Hlim && (unsigned)iw < (unsigned)Wlim;
+      if (p.ups) { ih >>= 1; iw >>= 1; }
+      long long off = ((long long)(nb[i] + ih) * p.W + iw) * ld + cc;
+      const uint16_t* g = v ? src + off : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(xs + (i * RPP + wid * 8) * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      bool v = kval && wok[j];
+      const uint16_t* g = v ? Wt + woff[j] + kcur : zero;
+      const int base_row = wrow_lds[j] - (lane >> 3);               // wave-uniform first row of this 1-KiB piece
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wsm + base_row * 128), 16, 0, 0);
+    }
+    kcur += 64;
+    cch += 64;
+    while (cch >= p.Cin) { cch -= p.Cin; ++tap; }
+  };
+
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  auto compute = [&](int stage) {
+    const unsigned char* xs = smem + stage * STAGE;
+    const unsigned char* wsm = xs + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int slot = ks * 2 + fhalf;
+      bf16x8 bfr[FM], afr[FN];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        int row = wm * WTM + b * 32 + frow;
+        bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < FN; ++a) {
+        int row = wn * WTN + a * 32 + frow;
+        afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // ---- ring: tile t lives in stage t % NST; up to NST-1 tiles are in flight ahead of the MFMAs -----------------------
+  const int ntile = (p.dbg & 8) ? 0 : kt_end - kt_begin;
+  if (ntile > 0) {
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+      if (issued < ntile) { issue_tile(s); ++issued; }
+    // wait for tile 0
+    if (issued >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cs = 0, is = (NST - 1) % NST;
+    for (int t = 0; t < ntile; ++t) {
+      const bool more = issued < ntile;
+      if (more) { if (!(p.dbg & 1)) issue_tile(is); ++issued; is = (is + 1 == NST) ? 0 : is + 1; }
+      if (!(p.dbg & 2)) compute(cs);
+      cs = (cs + 1 == NST) ? 0 : cs + 1;
+      // tile t+1 must have landed before anyone reads it: all but the newest (NST-2) tiles' DMAs retired
+      if (issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.y)[0] = 1.f; return; }
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
+}
+
+template <int BM, int BN, int WM, int WN, int NST>
+int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
+  k.tiles_m = (k.M + BM - 1) / BM;
+  k.tiles_n = (k.Cout + BN - 1) / BN;
+  const long long blocks = (long long)k.tiles_m * k.tiles_n * k.nbatch;
+  int splitk = 1;
+  if (blocks < min_blocks && k.nk >= 8 && k.ws) {
+    long long want = (256 + blocks - 1) / blocks;
+    splitk = (int)std::min<long long>(std::min<long long>(want, k.nk / 4), 16);
+    while (splitk > 1 && (long long)splitk * k.nbatch * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
+    if (splitk < 1) splitk = 1;
+  }
+  k.nk_per_split = (k.nk + splitk - 1) / splitk;
+  k.splitk = (k.nk + k.nk_per_split - 1) / k.nk_per_split;
+  constexpr int lds = NST * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, WM, WN, NST>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
+  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, WM, WN, NST>), grid, dim3(WM * WN * 64), lds, s, k);
+  if (k.splitk > 1) {
+    long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
+    int rb = (int)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
+  }
+  return ur::check_launch("ur_conv2d_nhwc");
+}
+
 }  // namespace
 
 extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
@@ -385,14 +713,34 @@ extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
   k.M = d->N * d->OH * d->OW; k.Ktot = d->KH * d->KW * k.Cin; k.nk = (k.Ktot + 63) / 64; k.nbatch = d->nbatch;
   k.bs_x = d->bs_x; k.bs_x2 = d->bs_x2; k.bs_w = d->bs_w; k.bs_bias = d->bs_bias; k.bs_y = d->bs_y; k.bs_r = d->bs_r; k.bias_img = d->bias_img_stride;
   UR_REQUIRE(k.M > 0, "empty problem");
+  { const char* e = getenv("UR_IGEMM_DBG"); k.dbg = e ? atoi(e) : 0; }
 
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * k.M * (double)k.Cout * k.Ktot * k.nbatch;
   const double bytes = 2.0 * ((double)k.M * k.Cin + (double)k.Cout * k.Ktot + (double)k.M * k.Cout) * k.nbatch;
   ur::ProfScope prof(d->KH == 3 ? "conv3x3_igemm" : "gemm1x1_igemm", flops, bytes, s);
-  if (pair) return launch_cfg<128, 128, 2, 2>(k, s);  // a|g 32-row blocks must sit in one wave tile
-  if (k.Cout <= 32) return launch_cfg<256, 32, 4, 1>(k, s);
-  if (k.Cout <= 64) return launch_cfg<128, 64, 2, 2>(k, s);
-  if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_cfg<128, 160, 4, 1>(k, s);
-  return launch_cfg<128, 128, 2, 2>(k, s);
+  static const bool use_v1 = getenv("UR_IGEMM_V1") != nullptr;
+  if (use_v1) {
+    if (pair) return launch_cfg<128, 128, 2, 2>(k, s);  // a|g 32-row blocks must sit in one wave tile
+    if (k.Cout <= 32) return launch_cfg<256, 32, 4, 1>(k, s);
+    if (k.Cout <= 64) return launch_cfg<128, 64, 2, 2>(k, s);
+    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_cfg<128, 160, 4, 1>(k, s);
+    return launch_cfg<128, 128, 2, 2>(k, s);
+  }
+  // v2 (LDS-DMA ring).  One workgroup per CU: pick the 256-row / 8-wave tiles when they still fill the chip.
+  if (k.Cout <= 32) return launch_glds<256, 32, 4, 1, 3>(k, s, 200);
+  if (k.Cout <= 64 && !pair) return launch_glds<128, 64, 2, 2, 3>(k, s, 200);
+  const bool n160 = !pair && k.Cout % 160 == 0 && k.Cout % 128 != 0;
+  const long long big_tiles = (long long)((k.M + 255) / 256) * ((k.Cout + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * k.nbatch;
+  if (big_tiles >= 160) {
+    if (n160) return launch_glds<256, 160, 8, 1, 3>(k, s, 0);
+    return launch_glds<256, 128, 4, 2, 3>(k, s, 0);
+  }
+  static const int small_mode = getenv("UR_IGEMM_SMALL") ? atoi(getenv("UR_IGEMM_SMALL")) : 2;
+  if (small_mode == 1) return launch_glds<128, 128, 2, 2, 2>(k, s, 400);
+  if (small_mode == 2) {
+    if (k.Cout % 160 == 0 && k.Cout % 128 != 0 && !pair) return launch_cfg<128, 160, 4, 1>(k, s);
+    return launch_cfg<128, 128, 2, 2>(k, s);
+  }
+  return launch_glds<128, 128, 2, 2, 3>(k, s, 200);
 }

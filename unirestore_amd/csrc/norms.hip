@@ -4,151 +4,171 @@
 
 namespace {
 
-// ---- GroupNorm pass 1: per-(image, channel) sum / sum-of-squares -----------------------------------
-// grid = (chunks, N).  Thread (r, v): channel vector v (8 channels), pixel rows r, r+R, ...  Block partials
-// are combined in LDS and leave as one fp64 atomic per channel per block.
+// ---- GroupNorm pass 1: per-(image, channel) sum / sum-of-squares -----------------------------------------------
+// grid = (pixel chunks, N, channel slabs).  A slab is CVS <= 32 channel vectors (8 channels each); thread (r, v)
+// owns vector v of the slab and pixel rows r, r+R, ... (R = 256/CVS), so a warp reads whole contiguous row pieces.
+// Block partials are combined with LDS atomics and leave as ONE fp64 atomic per channel per block.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ x, double* __restrict__ stats,
-                                                       int HW, int C, int pix_per_block, int c_off, int C_total) {
-  extern __shared__ float lds[];  // [2][C] when CV <= 256
+                                                       int HW, int C, int pix_per_block, int c_off, int C_total, int CVS) {
+  __shared__ float lds[2 * 256];
   const int n = blockIdx.y, t = threadIdx.x;
-  const int CV = C >> 3;
+  const int CV = C >> 3, R = 256 / CVS;
+  const int r = t / CVS, vl = t - r * CVS, v = blockIdx.z * CVS + vl;
   const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
-  const uint16_t* xi = x + (long long)n * HW * C;
+  for (int i = t; i < 2 * CVS * 8; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  if (r < R && v < CV) {
+    const uint16_t* xi = x + (long long)n * HW * C + v * 8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = p_begin + r; p < p_end; p += R) {
+      uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C);
+      float f[8];
+      unpack8(raw, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&lds[vl * 8 + e], s[e]);
+      atomicAdd(&lds[CVS * 8 + vl * 8 + e], q[e]);
+    }
+  }
+  __syncthreads();
   double* st = stats + ((long long)n * C_total + c_off) * 2;
-  if (CV <= 256) {
-    const int R = 256 / CV;
-    for (int i = t; i < 2 * C; i += 256) lds[i] = 0.f;
-    __syncthreads();
-    const int r = t / CV, v = t - r * CV;
-    if (r < R) {
-      float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int p = p_begin + r; p < p_end; p += R) {
-        uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C + v * 8);
-        float f[8];
-        unpack8(raw, f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&lds[v * 8 + e], s[e]);
-        atomicAdd(&lds[C + v * 8 + e], q[e]);
-      }
-    }
-    __syncthreads();
-    for (int c = t; c < C; c += 256) {
-      atomicAdd(&st[2 * c], (double)lds[c]);
-      atomicAdd(&st[2 * c + 1], (double)lds[C + c]);
-    }
-  } else {
-    for (int v = t; v < CV; v += 256) {
-      float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int p = p_begin; p < p_end; ++p) {
-        uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C + v * 8);
-        float f[8];
-        unpack8(raw, f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&st[2 * (v * 8 + e)], (double)s[e]);
-        atomicAdd(&st[2 * (v * 8 + e) + 1], (double)q[e]);
-      }
+  for (int i = t; i < CVS * 8; i += 256) {
+    const int c = blockIdx.z * CVS * 8 + i;
+    if (c < C) {
+      atomicAdd(&st[2 * c], (double)lds[i]);
+      atomicAdd(&st[2 * c + 1], (double)lds[CVS * 8 + i]);
     }
   }
 }
 
-// ---- GroupNorm pass 2: y = act(a[c]*x + b[c]); a/b rebuilt per block from the fp64 channel sums ----
-__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
-                                                       const double* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int HW, int C, int G, float eps,
-                                                       int silu, int pix_per_block, int c_off, int C_total) {
-  // C = channels of THIS source tensor; it occupies channels [c_off, c_off+C) of the C_total-wide (virtually
-  // concatenated) normalisation domain; y has row stride C_total.
-  extern __shared__ float lds[];  // a[C], b[C]
-  const int n = blockIdx.y, t = threadIdx.x;
-  const int cpg = C_total / G;
-  const double* st = stats + (long long)n * C_total * 2;
-  for (int cl = t; cl < C; cl += 256) {
-    const int c = c_off + cl;
-    const int g0 = (c / cpg) * cpg;
-    double s = 0.0, q = 0.0;
-    for (int j = 0; j < cpg; ++j) { s += st[2 * (g0 + j)]; q += st[2 * (g0 + j) + 1]; }
-    const double cnt = (double)cpg * HW;
-    const double mean = s / cnt;
-    double var = q / cnt - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    lds[cl] = rstd * ga;
-    lds[C + cl] = be - (float)mean * rstd * ga;
+// ---- GroupNorm pass 2 (tiny): per-image group statistics -> per-channel affine (a, b); re-zeroes the sums ----
+// grid = N, one block per image.  The fp64 sum buffer is zero at rest: this kernel consumes it and clears it, so
+// no zero-fill launch is needed per call.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(double* __restrict__ stats, float* __restrict__ ab,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int HW, int C, int G, float eps) {
+  extern __shared__ double gl[];  // gsum[G], gsq[G], then (float) mean[G], rstd[G]
+  const int n = blockIdx.x, t = threadIdx.x, cpg = C / G;
+  double* st = stats + (long long)n * C * 2;
+  for (int g = t; g < 2 * G; g += 256) gl[g] = 0.0;
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {                       // all threads, independent coalesced loads, LDS fp64 atomics
+    const double s = st[2 * c], q = st[2 * c + 1];
+    atomicAdd(&gl[c / cpg], s);
+    atomicAdd(&gl[G + c / cpg], q);
+    st[2 * c] = 0.0;                                       // leave the sums zero for the next call
+    st[2 * c + 1] = 0.0;
   }
   __syncthreads();
-  const int CV = C >> 3;
+  float* mr = reinterpret_cast<float*>(gl + 2 * G);
+  for (int g = t; g < G; g += 256) {
+    const double cnt = (double)cpg * HW, mean = gl[g] / cnt;
+    double var = gl[G + g] / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    mr[g] = (float)mean;
+    mr[G + g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  float* o = ab + (long long)n * C * 2;
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cpg;
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f, a = mr[G + g] * ga;
+    o[c] = a;
+    o[C + c] = be - mr[g] * a;
+  }
+}
+
+// ---- GroupNorm pass 3: y = act(a[c]*x + b[c]) ------------------------------------------------------------------
+// Same (pixel chunk, image, channel slab) decomposition; each thread keeps its 8 channels' (a, b) in registers.
+// C = channels of THIS source tensor; it occupies channels [c_off, c_off+C) of the C_total-wide (virtually
+// concatenated) normalisation domain; y has row stride C_total.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                       const float* __restrict__ ab, int HW, int C, int silu,
+                                                       int pix_per_block, int c_off, int C_total, int CVS) {
+  const int n = blockIdx.y, t = threadIdx.x;
+  const int CV = C >> 3, R = 256 / CVS;
+  const int r = t / CVS, v = blockIdx.z * CVS + (t - r * CVS);
+  if (r >= R || v >= CV) return;
+  const float* abn = ab + (long long)n * C_total * 2 + c_off + v * 8;
+  float a[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = abn[e]; b[e] = abn[C_total + e]; }
   const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
-  const long long base = (long long)n * HW * C;
-  const long long obase = (long long)n * HW * C_total + c_off;
-  const long long v_begin = (long long)p_begin * CV, v_end = (long long)p_end * CV;
-  for (long long i = v_begin + t; i < v_end; i += 256) {
-    const int v = (int)(i % CV);
-    const long long pix = i / CV;
-    uint4 raw = *reinterpret_cast<const uint4*>(x + base + i * 8);
+  const uint16_t* xi = x + (long long)n * HW * C + v * 8;
+  uint16_t* yo = y + (long long)n * HW * C_total + c_off + v * 8;
+  for (int p = p_begin + r; p < p_end; p += R) {
+    uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C);
     float f[8];
     unpack8(raw, f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float o = f[e] * lds[v * 8 + e] + lds[C + v * 8 + e];
+      float o = f[e] * a[e] + b[e];
       f[e] = silu ? silu_f(o) : o;
     }
-    *reinterpret_cast<uint4*>(y + obase + pix * C_total + v * 8) = pack8(f);
+    *reinterpret_cast<uint4*>(yo + (long long)p * C_total) = pack8(f);
   }
 }
 
-// ---- LayerNorm over C: one wave per row, row held in registers, exact two-pass variance -----------
-template <int VPL>  // vectors (8 elems) per lane
+// ---- LayerNorm over C: one wave per row, R rows per wave in flight, exact two-pass variance in registers --------
+template <int VPL, int R>  // vectors (8 elems) per lane, rows batched per wave
 __global__ __launch_bounds__(256) void ln_rows_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       long long rows, int C, float eps) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
   const int CV = C >> 3;
-  float f[VPL][8];
-  float s = 0.f;
+  uint4 raw[R][VPL];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int v = lane + j * 64;
+      const long long row = min(row0 + r, rows - 1);
+      raw[r][j] = (v < CV) ? *reinterpret_cast<const uint4*>(x + row * C + v * 8) : make_uint4(0, 0, 0, 0);
+    }
+  float ga[VPL][8], be[VPL][8];
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
     const int v = lane + j * 64;
-    if (v < CV) {
-      uint4 raw = *reinterpret_cast<const uint4*>(x + row * C + v * 8);
-      unpack8(raw, f[j]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += f[j][e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[j][e] = 0.f;
+    for (int e = 0; e < 8; ++e) {
+      ga[j][e] = (gamma && v < CV) ? gamma[v * 8 + e] : 1.f;
+      be[j][e] = (beta && v < CV) ? beta[v * 8 + e] : 0.f;
     }
   }
-  const float mean = wave_sum(s) / C;
-  float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < VPL; ++j)
-    if (lane + j * 64 < CV) {
+  for (int r = 0; r < R; ++r) {
+    if (row0 + r >= rows) break;
+    float f[VPL][8];
+    float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { float d = f[j][e] - mean; q += d * d; }
+    for (int j = 0; j < VPL; ++j) {
+      unpack8(raw[r][j], f[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += f[j][e];
     }
-  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    const int v = lane + j * 64;
-    if (v < CV) {
-      float o[8];
+    for (int j = 0; j < VPL; ++j)
+      if (lane + j * 64 < CV) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = v * 8 + e;
-        o[e] = (f[j][e] - mean) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+        for (int e = 0; e < 8; ++e) { float d = f[j][e] - mean; q += d * d; }
       }
-      *reinterpret_cast<uint4*>(y + row * C + v * 8) = pack8(o);
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int v = lane + j * 64;
+      if (v < CV) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f[j][e] - mean) * rstd * ga[j][e] + be[j][e];
+        *reinterpret_cast<uint4*>(y + (row0 + r) * C + v * 8) = pack8(o);
+      }
     }
   }
 }
@@ -182,31 +202,44 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 extern "C" {
 
 size_t ur_groupnorm_ws_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(double); }
+size_t ur_groupnorm_ab_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(float); }
 
 int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int N, int HW,
-                      int C1, int C2, int G, float eps, int silu, void* ws, ur_stream_t stream) {
-  UR_REQUIRE(x && y && ws, "null pointer");
+                      int C1, int C2, int G, float eps, int silu, void* ws, float* ab, ur_stream_t stream) {
+  UR_REQUIRE(x && y && ws && ab, "null pointer");
   const int C = C1 + (x2 ? C2 : 0);
   UR_REQUIRE(C1 % 8 == 0 && (!x2 || C2 % 8 == 0) && G > 0 && C % G == 0 && N > 0 && HW > 0, "C%8, C%G");
   UR_REQUIRE((size_t)C * 8 <= 64 * 1024, "C too large");
   hipStream_t s = (hipStream_t)stream;
   const double bytes = 2.0 * N * HW * (double)C;
   ur::ProfScope prof("groupnorm", 0.0, 3.0 * bytes, s);
-  ur::zero_async(ws, ur_groupnorm_ws_bytes(N, C), s);
-  // enough blocks to fill 256 CUs several times over, at least ~32 pixels per block
-  int chunks = (int)std::min<long long>(std::max<long long>(1, (2048 + N - 1) / N), (HW + 31) / 32);
-  int ppb = (HW + chunks - 1) / chunks;
-  chunks = (HW + ppb - 1) / ppb;
+  // ws = [N][C][2] fp64 sums, ZERO AT REST (the caller zero-fills once, the finalize kernel re-zeroes what it read);
+  // ab = [N][2][C] fp32 affine table (plain scratch; separate so it can never alias another call's sums)
+  double* stats = (double*)ws;
   const uint16_t* src[2] = {(const uint16_t*)x, (const uint16_t*)x2};
   const int cs[2] = {C1, x2 ? C2 : 0}, off[2] = {0, C1};
+  int chunks[2], ppb[2], cvs[2], slabs[2];
+  for (int i = 0; i < 2; ++i) {
+    if (cs[i] <= 0) continue;
+    const int cv = cs[i] / 8;
+    cvs[i] = cv < 32 ? cv : 32;                            // channel vectors per slab (<= 256 channels):
+    while (cv % cvs[i]) --cvs[i];                          // the largest divisor of CV that is <= 32 (no ragged slab)
+    slabs[i] = (cv + cvs[i] - 1) / cvs[i];
+    const int R = 256 / cvs[i];
+    // aim for >= ~2048 blocks (8 per CU) but keep >= 4 pixel rows per thread when the tensor is big enough
+    long long want = std::max<long long>(1, 2048 / ((long long)N * slabs[i]));
+    chunks[i] = (int)std::min<long long>(want, std::max(1, HW / (4 * R)));
+    ppb[i] = (HW + chunks[i] - 1) / chunks[i];
+    chunks[i] = (HW + ppb[i] - 1) / ppb[i];
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], stats, HW, cs[i], ppb[i], off[i], C,
+                       cvs[i]);
+  }
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), (size_t)G * (2 * sizeof(double) + 2 * sizeof(float)), s, stats, ab,
+                     gamma, beta, HW, C, G, eps);
   for (int i = 0; i < 2; ++i)
     if (cs[i] > 0)
-      hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, N), dim3(256), (size_t)2 * cs[i] * sizeof(float), s, src[i],
-                         (double*)ws, HW, cs[i], ppb, off[i], C);
-  for (int i = 0; i < 2; ++i)
-    if (cs[i] > 0)
-      hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, N), dim3(256), (size_t)2 * cs[i] * sizeof(float), s, src[i],
-                         (uint16_t*)y, (const double*)ws, gamma, beta, HW, cs[i], G, eps, silu, ppb, off[i], C);
+      hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], (uint16_t*)y, ab, HW, cs[i], silu,
+                         ppb[i], off[i], C, cvs[i]);
   return ur::check_launch("ur_groupnorm_nhwc");
 }
 
@@ -217,14 +250,15 @@ int ur_layernorm_rows(const void* x, void* y, const float* gamma, const float* b
   hipStream_t s = (hipStream_t)stream;
   ur::ProfScope prof("layernorm", 0.0, 4.0 * rows * (double)C, s);
   const int vpl = (C / 8 + 63) / 64;
-  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  constexpr int R = 4;
+  dim3 grid((unsigned)((rows + 4 * R - 1) / (4 * R))), block(256);
   const uint16_t* xi = (const uint16_t*)x;
   uint16_t* yo = (uint16_t*)y;
   switch (vpl) {
-    case 1: hipLaunchKernelGGL(ln_rows_kernel<1>, grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
-    case 2: hipLaunchKernelGGL(ln_rows_kernel<2>, grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
-    case 3: hipLaunchKernelGGL(ln_rows_kernel<3>, grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
-    default: hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
+    case 1: hipLaunchKernelGGL((ln_rows_kernel<1, R>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
+    case 2: hipLaunchKernelGGL((ln_rows_kernel<2, R>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
+    case 3: hipLaunchKernelGGL((ln_rows_kernel<3, R>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
+    default: hipLaunchKernelGGL((ln_rows_kernel<4, R>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
   }
   return ur::check_launch("ur_layernorm_rows");
 }

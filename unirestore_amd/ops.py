@@ -33,7 +33,14 @@ def workspace(dev, nbytes=192 << 20) -> torch.Tensor:
 def _gn_ws(dev, nbytes) -> torch.Tensor:
     key = (dev, "gn")
     if key not in _ws or _ws[key].numel() * 8 < nbytes:
-        _ws[key] = torch.empty(max(nbytes // 8, 1 << 16), dtype=torch.float64, device=dev)
+        _ws[key] = torch.zeros(max(nbytes // 8 + 1, 1 << 17), dtype=torch.float64, device=dev)   # zero at rest
+    return _ws[key]
+
+
+def _gn_ab(dev, nbytes) -> torch.Tensor:
+    key = (dev, "gn_ab")
+    if key not in _ws or _ws[key].numel() * 4 < nbytes:
+        _ws[key] = torch.empty(max(nbytes // 4 + 1, 1 << 18), dtype=torch.float32, device=dev)
     return _ws[key]
 
 
@@ -175,8 +182,9 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu=False
     hw = x.numel() // (n * c1)
     out = torch.empty((*x.shape[:-1], c1 + c2), dtype=BF16, device=x.device)
     ws = _gn_ws(x.device, lib.ur_groupnorm_ws_bytes(n, c1 + c2))
+    ab = _gn_ab(x.device, lib.ur_groupnorm_ab_bytes(n, c1 + c2))
     check(lib.ur_groupnorm_nhwc(x.data_ptr(), _ptr(x2), out.data_ptr(), _ptr(gamma), _ptr(beta), n, hw, c1, c2, groups, eps,
-                                int(silu), ws.data_ptr(), _stream()))
+                                int(silu), ws.data_ptr(), ab.data_ptr(), _stream()))
     return out
 
 
