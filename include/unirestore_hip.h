@@ -61,6 +61,8 @@ typedef struct ur_conv_desc {
   void* yt;             /* bf16 transposed output for columns >= n_split: [M/t_rows][Cout-n_split][t_ld] or NULL */
   float* colsum;        /* fp32 [N][nbatch*Cout_out] += colsum_scale * sum over the image's rows (atomic; fused
                            AdaptiveAvgPool2d(1), taskeditor.py:35) or NULL; batch index = channel group */
+  double* gn_stats;     /* fp64 [N][nbatch*Cout_out][2] += (sum, sum of squares) of the stored bf16 outputs per image and
+                           channel (atomic; statistics for the GroupNorm that consumes y) or NULL */
   float* workspace;     /* fp32 split-K scratch or NULL */
   size_t workspace_bytes;
   int N, H, W;          /* input dims (before upsample2x) */
@@ -76,6 +78,8 @@ typedef struct ur_conv_desc {
   float colsum_scale;
   int nbatch;           /* >= 1 */
   long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r; /* element strides per batch index */
+  int k_chunk_major;    /* 1: weight K index runs (64-channel chunk, tap, channel) instead of (tap, channel): the taps of
+                           one chunk are consecutive K tiles, so re-reads of a pixel hit L2 (needs C1, C1+C2 % 64 == 0) */
   long long bias_img_stride; /* 0: one bias row; else bias row of image n = m/(OH*OW) is bias + n*stride
                                 (per-sample time embeddings, unifie.py:91-105) */
 } ur_conv_desc;
@@ -92,8 +96,11 @@ size_t ur_groupnorm_ws_bytes(int N, int C); /* fp64 channel sums: zero on first 
 size_t ur_groupnorm_ab_bytes(int N, int C); /* fp32 per-(image, channel) affine table: plain scratch */
 /* x2/C2 (optional): second source tensor, virtually concatenated after x's C1 channels (UNet up path:
  * GroupNorm over torch.cat([sample, skip]), base_model.py:189,197); y is [N,HW,C1+C2]. */
+/* pre1 / pre2 (optional): channel sums of x / x2 already produced by ur_conv_desc.gn_stats ([N][C1][2] / [N][C2][2]);
+ * when given, the statistics pass over that tensor is skipped (they are read, not cleared). */
 int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int N, int HW,
-                      int C1, int C2, int G, float eps, int silu, void* ws, float* ab, ur_stream_t stream);
+                      int C1, int C2, int G, float eps, int silu, void* ws, float* ab, const double* pre1,
+                      const double* pre2, ur_stream_t stream);
 /* LayerNorm over the last dim of [rows, C] bf16 (nn.LayerNorm in BasicTransformerBlock; timm LayerNorm2d
  * in NAFBlock, nafnet_arch.py:97-98, which is LayerNorm-over-C in NHWC). */
 int ur_layernorm_rows(const void* x, void* y, const float* gamma, const float* beta, long long rows, int C,

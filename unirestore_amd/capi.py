@@ -16,7 +16,7 @@ class ConvDesc(C.Structure):
     """Mirror of `ur_conv_desc` (field order and types must match the header exactly)."""
     _fields_ = [
         ("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
-        ("y", C.c_void_p), ("yt", C.c_void_p), ("colsum", C.c_void_p), ("workspace", C.c_void_p),
+        ("y", C.c_void_p), ("yt", C.c_void_p), ("colsum", C.c_void_p), ("gn_stats", C.c_void_p), ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
         ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
         ("C1", C.c_int), ("ldx", C.c_int), ("C2", C.c_int), ("ldx2", C.c_int),
@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("out_scale", C.c_float), ("colsum_scale", C.c_float),
         ("nbatch", C.c_int),
         ("bs_x", C.c_longlong), ("bs_x2", C.c_longlong), ("bs_w", C.c_longlong), ("bs_bias", C.c_longlong),
-        ("bs_y", C.c_longlong), ("bs_r", C.c_longlong), ("bias_img_stride", C.c_longlong),
+        ("bs_y", C.c_longlong), ("bs_r", C.c_longlong), ("k_chunk_major", C.c_int), ("bias_img_stride", C.c_longlong),
     ]
 
 
@@ -41,7 +41,7 @@ SIGNATURES = {
     "ur_conv2d_nhwc": (_I, [C.POINTER(ConvDesc), _P]),
     "ur_groupnorm_ws_bytes": (_SZ, [_I, _I]),
     "ur_groupnorm_ab_bytes": (_SZ, [_I, _I]),
-    "ur_groupnorm_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P]),
+    "ur_groupnorm_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
     "ur_layernorm_rows": (_I, [_P, _P, _P, _P, _LL, _I, _F, _P]),
     "ur_softmax_rows_f32": (_I, [_P, _P, _LL, _I, _I, _P]),
     "ur_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL, _F, _P]),

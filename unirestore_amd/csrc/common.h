@@ -61,6 +61,8 @@ int check_launch(const char* what);
 // Zero `bytes` (multiple of 4) with a kernel node: hipMemsetAsync memset nodes misbehaved under hipGraph
 // replay on small private-pool buffers (ROCm 7.2), so the library never emits memset nodes.
 void zero_async(void* ptr, size_t bytes, hipStream_t s);
+// per-(image, channel) sum / sum-of-squares of a dense NHWC bf16 tensor, accumulated into fp64 stats[N][C][2] (norms.hip)
+int gn_stats_launch(const void* x, double* stats, int N, int HW, int C, hipStream_t s);
 
 // Live timing: one (start, stop) hipEvent pair around each launch, on the launch stream.
 struct ProfScope {

@@ -23,14 +23,15 @@ namespace {
 
 struct ConvK {
   const uint16_t* x; const uint16_t* x2; const uint16_t* w; const float* bias; const uint16_t* res;
-  void* y; uint16_t* yt; float* colsum; float* ws;
+  void* y; uint16_t* yt; float* colsum; float* ws; double* gn_stats;
   int N, H, W, C1, ldx, C2, ldx2, Cin, Cout, ldw, ldy, ldr, KH, KW, stride, pad_t, pad_l, OH, OW, OHW;
   int ups, act, out_f32, n_split, t_rows, t_ld;
   float out_scale, colsum_scale;
   int M, Ktot, nk, tiles_m, tiles_n, splitk, nk_per_split, nbatch;
   long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r, bias_img;
   size_t ws_bytes_;
-  int dbg;
+  int dbg, gn_fused, staged_ok_;
+  int kcm;   // 1: K runs (64-channel chunk, tap, channel) - the 9 taps of a chunk are consecutive K tiles (L2 reuse)
 };
 
 __device__ __forceinline__ bool is_pair_act(int act) { return act == UR_ACT_GEGLU || act == UR_ACT_GATE; }
@@ -183,9 +184,12 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ConvK& p, f32x16 (&a
 // inside each quad's branch serialised ~20 memory latencies per lane.)
 template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT>
 __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
-                                               int gb, int sz, unsigned char* smem) {
+                                               int gb, int sz, unsigned char* smem, bool owner = true) {
+  // owner: this wave holds accumulator fragments (false for the loader waves of the warp-specialised kernel,
+  // which still take part in the barriers and the tile copies)
   const int fhalf = lane >> 5, mrow = lane & 31;
   if (p.splitk > 1) {
+    if (!owner) return;
     float* ws = p.ws + ((long long)(sz * p.nbatch + gb) * p.M) * p.Cout;
 #pragma unroll
     for (int a = 0; a < FN; ++a)
@@ -204,18 +208,20 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   }
   const bool pair = is_pair_act(p.act);
   constexpr int SROW = BN * 2 + 8;                       // staged row stride in bytes (+8 spreads the ds_write_b64 banks)
-  const bool staged = p.y && !p.out_f32 && !p.colsum && !p.bias_img && ((p.ldy | p.bs_y) & 7) == 0 &&
-                      (!p.res || ((p.ldr | p.bs_r) & 7) == 0) && BN >= 32;
+  const bool staged = p.staged_ok_ && BN >= 32;        // host-evaluated: bf16 y, 16-byte aligned rows, no colsum / per-image bias
   if (!staged) {
-    igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
+    if (owner) igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
     return;
   }
   const int c0 = pair ? (n0 >> 1) : n0;                  // first output column of this tile
   const int ncols = pair ? BN / 2 : BN;
   const int cmax = min(p.yt ? p.n_split : (pair ? p.Cout / 2 : p.Cout), c0 + ncols) - c0;     // valid output columns here
   float* sbias = reinterpret_cast<float*>(smem + BM * SROW);                                   // BN floats (GEMM-N order)
+  float* facc = sbias + BN;                                                                    // [2][BN] fused GroupNorm sums
   for (int i = threadIdx.x; i < BN; i += NT)
     sbias[i] = (p.bias && n0 + i < p.Cout) ? p.bias[gb * p.bs_bias + n0 + i] : 0.f;
+  if (p.gn_fused)
+    for (int i = threadIdx.x; i < 2 * BN; i += NT) facc[i] = 0.f;
   if (p.res) {                                            // residual tile -> LDS, coalesced
     uint16_t* rb = const_cast<uint16_t*>(p.res) + gb * p.bs_r;
     if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, true>(rb, p.ldr, smem, m0, p.M, c0, cmax);
@@ -223,6 +229,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   }
   __syncthreads();
   const bool has_res = p.res != nullptr;
+  if (owner)
 #pragma unroll
   for (int a = 0; a < FN; ++a) {
     if (pair && (a & 1)) continue;
@@ -270,6 +277,31 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   }
   if (p.dbg & 16) return;
   __syncthreads();
+  if (p.gn_fused) {
+    // Fused GroupNorm statistics of the tile just produced (exactly the bf16 values the consumer will read):
+    // thread (g, cp) sums column pair cp over row group g from LDS, row groups meet in LDS, then ONE fp64 atomic
+    // per (column, moment) per workgroup.  The host only sets gn_fused when a tile never straddles two images.
+    const int CP = ncols >> 1, NG = NT / CP, RGN = (BM + NG - 1) / NG;
+    const int cp = threadIdx.x % CP, g = threadIdx.x / CP;
+    if (g < NG && cp * 2 < cmax) {
+      const int r0 = g * RGN, r1 = min(min(BM, r0 + RGN), p.M - m0);
+      float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+      for (int r = r0; r < r1; ++r) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * SROW + cp * 4);
+        const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
+        s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+      }
+      atomicAdd(&facc[cp * 2], s0); atomicAdd(&facc[cp * 2 + 1], s1);
+      atomicAdd(&facc[BN + cp * 2], q0); atomicAdd(&facc[BN + cp * 2 + 1], q1);
+    }
+    __syncthreads();
+    const int ctot = pair ? p.Cout / 2 : p.Cout;
+    double* st = p.gn_stats + ((long long)(m0 / p.OHW) * p.nbatch * ctot + (long long)gb * ctot + c0) * 2;
+    for (int i = threadIdx.x; i < cmax; i += NT) {
+      atomicAdd(&st[2 * i], (double)facc[i]);
+      atomicAdd(&st[2 * i + 1], (double)facc[BN + i]);
+    }
+  }
   uint16_t* yb = reinterpret_cast<uint16_t*>(p.y) + gb * p.bs_y;
   if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, false>(yb, p.ldy, smem, m0, p.M, c0, cmax);
   else tile_copy<BM, BN, NT, SROW, false>(yb, p.ldy, smem, m0, p.M, c0, cmax);
@@ -328,6 +360,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
   const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
   int kcur = kt_begin * 64 + chunk * 8;
   int tap = kcur / p.Cin, cch = kcur - tap * p.Cin;
+  const int ntap = p.KH * p.KW;
+  if (p.kcm) { tap = kt_begin % ntap; cch = (kt_begin / ntap) * 64 + chunk * 8; }
 
   uint4 xr[XP], wr[WP];
   auto load_tile = [&]() {
@@ -355,8 +389,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
       wr[j] = v ? val : make_uint4(0, 0, 0, 0);
     }
     kcur += 64;
-    cch += 64;
-    while (cch >= p.Cin) { cch -= p.Cin; ++tap; }
+    if (p.kcm) { if (++tap == ntap) { tap = 0; cch += 64; } }
+    else { cch += 64; while (cch >= p.Cin) { cch -= p.Cin; ++tap; } }
   };
   auto store_tile = [&](int stage) {
     unsigned char* xs = smem + stage * STAGE;
@@ -473,6 +507,7 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   k.splitk = splitk;
   k.nk_per_split = (k.nk + splitk - 1) / splitk;
   k.splitk = (k.nk + k.nk_per_split - 1) / k.nk_per_split;
+  k.gn_fused = k.gn_stats && k.staged_ok_ && k.splitk == 1 && BN >= 32 && (k.OHW % BM) == 0;
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
@@ -558,6 +593,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
   const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
   int kcur = kt_begin * 64 + chunk * 8;
   int tap = kcur / p.Cin, cch = kcur - tap * p.Cin;
+  const int ntap = p.KH * p.KW;
+  if (p.kcm) { tap = kt_begin % ntap; cch = (kt_begin / ntap) * 64 + chunk * 8; }
 
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -584,11 +621,12 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
       bool v = kval && wok[j];
       const uint16_t* g = v ? Wt + woff[j] + kcur : zero;
       const int base_row = wrow_lds[j] - (lane >> 3);               // wave-uniform first row of this 1-KiB piece
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wsm + base_row * 128), 16, 0, 0);
+      if (p.dbg & 128) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wsm + base_row * 128), 16, 0, 2);   // nt: stream past L1
+      else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wsm + base_row * 128), 16, 0, 0);
     }
     kcur += 64;
-    cch += 64;
-    while (cch >= p.Cin) { cch -= p.Cin; ++tap; }
+    if (p.kcm) { if (++tap == ntap) { tap = 0; cch += 64; } }
+    else { cch += 64; while (cch >= p.Cin) { cch -= p.Cin; ++tap; } }
   };
 
   f32x16 acc[FN][FM];
@@ -666,6 +704,7 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
   }
   k.nk_per_split = (k.nk + splitk - 1) / splitk;
   k.splitk = (k.nk + k.nk_per_split - 1) / k.nk_per_split;
+  k.gn_fused = k.gn_stats && k.staged_ok_ && k.splitk == 1 && BN >= 32 && (k.OHW % BM) == 0;
   constexpr int lds = NST * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
@@ -681,6 +720,271 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
   }
   return ur::check_launch("ur_conv2d_nhwc");
+}
+
+
+// =====================================================================================================================
+// v3 main loop: warp-specialised.  WM*WN CONSUMER waves only read fragments from LDS and issue MFMAs; NPW PRODUCER
+// waves only do address arithmetic and LDS-DMA (global_load_lds_dwordx4) into the NST-deep ring.  Both roles meet at
+// one raw s_barrier per K tile, so on every SIMD the loader's VALU/VMEM issue interleaves with the consumers' MFMA
+// stream instead of alternating with it in lockstep (the v2 kernel spent 61 % of its wave-cycles parked in waits).
+//   barrier t : producers have waited (counted vmcnt) until tile t landed; consumers have finished tile t-1.
+//   after it  : consumers compute tile t (stage t % NST); producers refill stage (t+2) % NST == (t-1) % NST.
+template <int BM, int BN, int WM, int WN, int NPW, int NST>
+__global__ __launch_bounds__((WM* WN + NPW) * 64) void igemm_ws_kernel(const ConvK p) {
+  constexpr int NCW = WM * WN, NT = (NCW + NPW) * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
+  constexpr int PIECES = (BM + BN) / 8, NP = (PIECES + NPW - 1) / NPW;   // 1-KiB pieces (8 rows) per tile / per producer wave
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(BM % 32 == 0 && BN % 32 == 0 && (NST == 2 || NST == 3), "tile shape / ring depth");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool consumer = wid < NCW;
+  const int wm = consumer ? wid % WM : 0, wn = consumer ? wid / WM : 0;
+  const int gb = blockIdx.y, sz = blockIdx.z;
+  int id = blockIdx.x;
+  {
+    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kt_begin = sz * p.nk_per_split;
+  const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
+  const int ntile = kt_end - kt_begin;
+
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  if (!consumer) {
+    // ------------------------------------------------------------------ PRODUCER -------------------------------------
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int pw = wid - NCW;
+    const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
+    const uint16_t* __restrict__ X2 = p.x2 ? p.x2 + gb * p.bs_x2 : nullptr;
+    const uint16_t* __restrict__ Wt = p.w + gb * p.bs_w;
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+    const int lr = lane >> 3, ps = lane & 7;               // row inside the piece, physical 16-B slot
+    // piece i of this wave = global piece pw + i*NPW; rows [piece*8, piece*8+8) of the (X | W) stage image.
+    // All per-tile address work is 32-bit: element offsets from the tensor base (host checks < 2^31 elements).
+    //   X row: pix = (n*H + ih0)*W + iw0 (pixel index of tap (0,0); may be "negative" at the border, only used when
+    //          the tap is in range), ih0/iw0 for the range check (an out-of-range ROW gets ih0 = -2^20);
+    //   W row: pix = row*ldw, ih0 = 0 valid / -2^20 invalid.
+    int pix[NP], ih0[NP], iw0[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = min(pw + i * NPW, PIECES - 1);     // a surplus slot repeats the last piece (identical bytes)
+      const int row = piece * 8 + lr;
+      if (row < BM) {
+        const int m = m0 + row;
+        const bool okr = m < p.M;
+        const int mm = okr ? m : 0;
+        const int n = mm / p.OHW, rem = mm - n * p.OHW;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        ih0[i] = okr ? oh * p.stride - p.pad_t : -(1 << 20);
+        iw0[i] = ow * p.stride - p.pad_l;
+        pix[i] = p.ups ? n * p.H : (n * p.H + ih0[i]) * p.W + iw0[i];
+      } else {
+        const int wr = n0 + row - BM;
+        const bool okr = wr < p.Cout;
+        ih0[i] = okr ? 0 : -(1 << 20);
+        iw0[i] = 0;
+        pix[i] = (okr ? wr : 0) * p.ldw;
+      }
+    }
+    const int Hlim = p.ups ? p.H * 2 : p.H, Wlim = p.ups ? p.W * 2 : p.W;
+    // logical K chunk of this lane: ps ^ ((row>>1)&7) with row = piece*8 + lr  ->  depends on the piece's parity only
+    int kc[2], tap[2], cch[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int chunk = ps ^ (((par * 8 + lr) >> 1) & 7);
+      kc[par] = kt_begin * 64 + chunk * 8;
+      tap[par] = kc[par] / p.Cin;
+      cch[par] = kc[par] - tap[par] * p.Cin;
+      if (p.kcm) { tap[par] = kt_begin % (p.KH * p.KW); cch[par] = (kt_begin / (p.KH * p.KW)) * 64 + chunk * 8; }
+    }
+    auto issue_tile = [&](int stage) {
+      unsigned char* st = smem + stage * STAGE;
+      // once per tile (per parity): tap decode, source select, tap offset
+      int dy[2], dx[2], toff[2], ld[2];
+      const uint16_t* src[2];
+      bool kv[2];
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        kv[par] = kc[par] < p.Ktot;
+        dy[par] = (p.KW == 1) ? 0 : (tap[par] * 11) >> 5;
+        dx[par] = tap[par] - dy[par] * p.KW;
+        int cc = cch[par];
+        src[par] = X1; ld[par] = p.ldx;
+        if (cc >= p.C1) { src[par] = X2; ld[par] = p.ldx2; cc -= p.C1; }
+        toff[par] = p.ups ? cc : (dy[par] * p.W + dx[par]) * ld[par] + cc;
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int piece = min(pw + i * NPW, PIECES - 1);
+        const int par = piece & 1;
+        const uint16_t* g = zero;
+        if (piece * 8 < BM) {                                 // X piece (wave-uniform branch)
+          const int ih = ih0[i] + dy[par], iw = iw0[i] + dx[par];
+          const bool v = kv[par] && (unsigned)ih < (unsigned)Hlim && (unsigned)iw < (unsigned)Wlim;
+          const int off = p.ups ? ((pix[i] + (ih >> 1)) * p.W + (iw >> 1)) * ld[par] + toff[par]
+                                : pix[i] * ld[par] + toff[par];
+          if (v) g = src[par] + off;
+        } else {
+          if (kv[par] && ih0[i] == 0) g = Wt + (pix[i] + kc[par]);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + piece * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        kc[par] += 64;
+        if (p.kcm) { if (++tap[par] == p.KH * p.KW) { tap[par] = 0; cch[par] += 64; } }
+        else { cch[par] += 64; while (cch[par] >= p.Cin) { cch[par] -= p.Cin; ++tap[par]; } }
+      }
+    };
+    if (ntile > 0) {
+      int issued = 0;
+      issue_tile(0); ++issued;
+      if (NST == 3 && ntile > 1) { issue_tile(1); ++issued; }
+      if (issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                      // barrier 0: tile 0 landed
+      int is = (NST - 1) % NST;
+      long long c_issue = 0, c_wait = 0, c_bar = 0;
+      const bool prof = (p.dbg & 64) && blockIdx.x == 17 && pw == 0;
+      for (int t = 0; t < ntile; ++t) {
+        long long t0 = prof ? clock64() : 0;
+        if (issued < ntile) {
+          issue_tile(is); ++issued; is = (is + 1 == NST) ? 0 : is + 1;
+          long long t1 = prof ? clock64() : 0;
+          if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");   // tile t+1 landed (only t+2 in flight)
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // 2-stage ring: tile t+1 itself
+          if (prof) { long long t2 = clock64(); c_issue += t1 - t0; c_wait += t2 - t1; t0 = t2; }
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (prof) { long long t2 = clock64(); c_wait += t2 - t0; t0 = t2; }
+        }
+        __builtin_amdgcn_s_barrier();                                    // barrier t+1
+        if (prof) c_bar += clock64() - t0;
+      }
+      if (prof && lane == 0) { p.ws[0] = (float)c_issue; p.ws[1] = (float)c_wait; p.ws[2] = (float)c_bar; p.ws[3] = (float)ntile; }
+    }
+  } else {
+    // ------------------------------------------------------------------ CONSUMER -------------------------------------
+    const int frow = lane & 31, fhalf = lane >> 5;
+    if (ntile > 0) {
+      __builtin_amdgcn_s_barrier();                                      // barrier 0
+      int cs = 0;
+      long long c_comp = 0, c_bar = 0;
+      const bool prof = (p.dbg & 64) && blockIdx.x == 17 && wid == 0;
+      for (int t = 0; t < ntile; ++t) {
+        const long long t0 = prof ? clock64() : 0;
+        const unsigned char* xs = smem + cs * STAGE;
+        const unsigned char* wsm = xs + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int slot = ks * 2 + fhalf;
+          bf16x8 bfr[FM], afr[FN];
+#pragma unroll
+          for (int b = 0; b < FM; ++b) {
+            const int row = wm * WTM + b * 32 + frow;
+            bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+          }
+#pragma unroll
+          for (int a = 0; a < FN; ++a) {
+            const int row = wn * WTN + a * 32 + frow;
+            afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+          }
+#pragma unroll
+          for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+        cs = (cs + 1 == NST) ? 0 : cs + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        long long t1 = 0;
+        if (prof) { asm volatile("" ::"v"(acc[0][0][0])); t1 = clock64(); c_comp += t1 - t0; }
+        __builtin_amdgcn_s_barrier();                                    // barrier t+1: done reading stage t % NST
+        if (prof) c_bar += clock64() - t1;
+      }
+      if (prof && lane == 0) { p.ws[4] = (float)c_comp; p.ws[5] = (float)c_bar; }
+    }
+  }
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem, consumer);
+}
+
+template <int BM, int BN, int WM, int WN, int NPW, int NST = 3>
+int launch_ws(ConvK& k, hipStream_t s) {
+  k.tiles_m = (k.M + BM - 1) / BM;
+  k.tiles_n = (k.Cout + BN - 1) / BN;
+  k.splitk = 1;
+  k.nk_per_split = k.nk;
+  k.gn_fused = k.gn_stats && k.staged_ok_ && BN >= 32 && (k.OHW % BM) == 0;
+  constexpr int lds = NST * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ws_kernel<BM, BN, WM, WN, NPW, NST>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, 1);
+  hipLaunchKernelGGL((igemm_ws_kernel<BM, BN, WM, WN, NPW, NST>), grid, dim3((WM * WN + NPW) * 64), lds, s, k);
+  return ur::check_launch("ur_conv2d_nhwc");
+}
+
+int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
+  static const bool use_v1 = getenv("UR_IGEMM_V1") != nullptr;
+  if (use_v1) {
+    if (pair) return launch_cfg<128, 128, 2, 2>(k, s);  // a|g 32-row blocks must sit in one wave tile
+    if (k.Cout <= 32) return launch_cfg<256, 32, 4, 1>(k, s);
+    if (k.Cout <= 64) return launch_cfg<128, 64, 2, 2>(k, s);
+    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_cfg<128, 160, 4, 1>(k, s);
+    return launch_cfg<128, 128, 2, 2>(k, s);
+  }
+  // v2 (LDS-DMA ring).  One workgroup per CU: pick the 256-row / 8-wave tiles when they still fill the chip.
+  if (k.Cout <= 32) return launch_glds<256, 32, 4, 1, 3>(k, s, 200);
+  if (k.Cout <= 64 && !pair) return launch_glds<128, 64, 2, 2, 3>(k, s, 200);
+  const bool n160 = !pair && k.Cout % 160 == 0 && k.Cout % 128 != 0;
+  const long long big_tiles = (long long)((k.M + 255) / 256) * ((k.Cout + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * k.nbatch;
+  if (big_tiles >= 160) {
+    static const bool no_ws = getenv("UR_IGEMM_WS") == nullptr;   // warp-specialised variant is opt-in (slower end to end)
+    if (no_ws) {
+      if (n160) return launch_glds<256, 160, 8, 1, 3>(k, s, 0);
+      return launch_glds<256, 128, 4, 2, 3>(k, s, 0);
+    }
+    static const int npw = getenv("UR_IGEMM_NPW") ? atoi(getenv("UR_IGEMM_NPW")) : 4;
+    static const int big = getenv("UR_IGEMM_BIG") ? atoi(getenv("UR_IGEMM_BIG")) : 0;
+    if (big == 3) {   // 4 consumer waves with 64-row x full-width wave tiles (fewer LDS fragment bytes per MFMA) + 4 producers
+      if (n160) return launch_ws<256, 160, 4, 1, 4>(k, s);
+      return launch_ws<256, 128, 4, 1, 4>(k, s);
+    }
+    if (npw == 8) {
+      if (n160) return launch_ws<256, 160, 8, 1, 8>(k, s);
+      return launch_ws<256, 128, 4, 2, 8>(k, s);
+    }
+    if (n160) return launch_ws<256, 160, 8, 1, 4>(k, s);
+    return launch_ws<256, 128, 4, 2, 4>(k, s);
+  }
+  static const int exp_mode = getenv("UR_IGEMM_EXP") ? atoi(getenv("UR_IGEMM_EXP")) : 0;
+  if (exp_mode == 1 && !pair) {
+    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_glds<128, 160, 4, 1, 2>(k, s, 0);
+    return launch_glds<128, 128, 2, 2, 2>(k, s, 0);
+  }
+  static const int small_mode = getenv("UR_IGEMM_SMALL") ? atoi(getenv("UR_IGEMM_SMALL")) : 2;
+  if (small_mode == 1) return launch_glds<128, 128, 2, 2, 2>(k, s, 400);
+  if (small_mode == 2) {
+    if (k.Cout % 160 == 0 && k.Cout % 128 != 0 && !pair) return launch_cfg<128, 160, 4, 1>(k, s);
+    return launch_cfg<128, 128, 2, 2>(k, s);
+  }
+  return launch_glds<128, 128, 2, 2, 3>(k, s, 200);
 }
 
 }  // namespace
@@ -713,34 +1017,26 @@ extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
   k.M = d->N * d->OH * d->OW; k.Ktot = d->KH * d->KW * k.Cin; k.nk = (k.Ktot + 63) / 64; k.nbatch = d->nbatch;
   k.bs_x = d->bs_x; k.bs_x2 = d->bs_x2; k.bs_w = d->bs_w; k.bs_bias = d->bs_bias; k.bs_y = d->bs_y; k.bs_r = d->bs_r; k.bias_img = d->bias_img_stride;
   UR_REQUIRE(k.M > 0, "empty problem");
+  UR_REQUIRE((long long)d->N * d->H * d->W * (long long)std::max(d->ldx, d->ldx2) < (1ll << 31) &&
+                 (long long)d->Cout * d->ldw < (1ll << 31), "tensor too large for 32-bit element offsets");
   { const char* e = getenv("UR_IGEMM_DBG"); k.dbg = e ? atoi(e) : 0; }
 
+  k.kcm = d->k_chunk_major;
+  UR_REQUIRE(!k.kcm || (k.Cin % 64 == 0 && d->C1 % 64 == 0), "k_chunk_major needs C1 and C1+C2 to be multiples of 64");
+  k.gn_stats = d->gn_stats;
+  k.staged_ok_ = d->y && !d->out_f32 && !d->colsum && !d->bias_img_stride && ((d->ldy | d->bs_y) & 7) == 0 &&
+                 (!d->residual || ((d->ldr | d->bs_r) & 7) == 0);
+  UR_REQUIRE(!d->gn_stats || (d->y && !d->out_f32 && !d->yt), "gn_stats needs a plain bf16 output");
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * k.M * (double)k.Cout * k.Ktot * k.nbatch;
   const double bytes = 2.0 * ((double)k.M * k.Cin + (double)k.Cout * k.Ktot + (double)k.M * k.Cout) * k.nbatch;
   ur::ProfScope prof(d->KH == 3 ? "conv3x3_igemm" : "gemm1x1_igemm", flops, bytes, s);
-  static const bool use_v1 = getenv("UR_IGEMM_V1") != nullptr;
-  if (use_v1) {
-    if (pair) return launch_cfg<128, 128, 2, 2>(k, s);  // a|g 32-row blocks must sit in one wave tile
-    if (k.Cout <= 32) return launch_cfg<256, 32, 4, 1>(k, s);
-    if (k.Cout <= 64) return launch_cfg<128, 64, 2, 2>(k, s);
-    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_cfg<128, 160, 4, 1>(k, s);
-    return launch_cfg<128, 128, 2, 2>(k, s);
+  const int rc = dispatch_conv(k, s, pair);
+  if (rc != UR_OK) return rc;
+  if (k.gn_stats && !k.gn_fused) {   // this launch could not fuse the statistics: one extra pass over the output
+    const int ctot = (pair ? k.Cout / 2 : k.Cout) * k.nbatch;
+    UR_REQUIRE(k.ldy == ctot, "gn_stats fallback needs a dense output (ldy == channels)");
+    return ur::gn_stats_launch(k.y, k.gn_stats, k.N, k.OHW, ctot, s);
   }
-  // v2 (LDS-DMA ring).  One workgroup per CU: pick the 256-row / 8-wave tiles when they still fill the chip.
-  if (k.Cout <= 32) return launch_glds<256, 32, 4, 1, 3>(k, s, 200);
-  if (k.Cout <= 64 && !pair) return launch_glds<128, 64, 2, 2, 3>(k, s, 200);
-  const bool n160 = !pair && k.Cout % 160 == 0 && k.Cout % 128 != 0;
-  const long long big_tiles = (long long)((k.M + 255) / 256) * ((k.Cout + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * k.nbatch;
-  if (big_tiles >= 160) {
-    if (n160) return launch_glds<256, 160, 8, 1, 3>(k, s, 0);
-    return launch_glds<256, 128, 4, 2, 3>(k, s, 0);
-  }
-  static const int small_mode = getenv("UR_IGEMM_SMALL") ? atoi(getenv("UR_IGEMM_SMALL")) : 2;
-  if (small_mode == 1) return launch_glds<128, 128, 2, 2, 2>(k, s, 400);
-  if (small_mode == 2) {
-    if (k.Cout % 160 == 0 && k.Cout % 128 != 0 && !pair) return launch_cfg<128, 160, 4, 1>(k, s);
-    return launch_cfg<128, 128, 2, 2>(k, s);
-  }
-  return launch_glds<128, 128, 2, 2, 3>(k, s, 200);
+  return UR_OK;
 }

@@ -49,18 +49,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
 // no zero-fill launch is needed per call.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(double* __restrict__ stats, float* __restrict__ ab,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          int HW, int C, int G, float eps) {
+                                                          int HW, int C, int G, float eps, const double* __restrict__ pre1,
+                                                          const double* __restrict__ pre2, int C1) {
   extern __shared__ double gl[];  // gsum[G], gsq[G], then (float) mean[G], rstd[G]
   const int n = blockIdx.x, t = threadIdx.x, cpg = C / G;
   double* st = stats + (long long)n * C * 2;
   for (int g = t; g < 2 * G; g += 256) gl[g] = 0.0;
   __syncthreads();
   for (int c = t; c < C; c += 256) {                       // all threads, independent coalesced loads, LDS fp64 atomics
-    const double s = st[2 * c], q = st[2 * c + 1];
+    // channel c comes from the producer's fused sums (pre1 / pre2, read-only) or from this call's own pass (st)
+    const double* src = st + 2 * c;
+    bool own = true;
+    if (c < C1 && pre1) { src = pre1 + ((long long)n * C1 + c) * 2; own = false; }
+    if (c >= C1 && pre2) { src = pre2 + ((long long)n * (C - C1) + (c - C1)) * 2; own = false; }
+    const double s = src[0], q = src[1];
     atomicAdd(&gl[c / cpg], s);
     atomicAdd(&gl[G + c / cpg], q);
-    st[2 * c] = 0.0;                                       // leave the sums zero for the next call
-    st[2 * c + 1] = 0.0;
+    if (own) { st[2 * c] = 0.0; st[2 * c + 1] = 0.0; }     // leave the internal sums zero for the next call
   }
   __syncthreads();
   float* mr = reinterpret_cast<float*>(gl + 2 * G);
@@ -199,13 +204,29 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
+namespace ur {
+int gn_stats_launch(const void* x, double* stats, int N, int HW, int C, hipStream_t s) {
+  const int cv = C / 8;
+  int cvs = cv < 32 ? cv : 32;
+  while (cv % cvs) --cvs;
+  const int slabs = cv / cvs, R = 256 / cvs;
+  long long want = std::max<long long>(1, 2048 / ((long long)N * slabs));
+  int chunks = (int)std::min<long long>(want, std::max(1, HW / (4 * R)));
+  const int ppb = (HW + chunks - 1) / chunks;
+  chunks = (HW + ppb - 1) / ppb;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, N, slabs), dim3(256), 0, s, (const uint16_t*)x, stats, HW, C, ppb, 0, C, cvs);
+  return check_launch("gn_stats");
+}
+}  // namespace ur
+
 extern "C" {
 
 size_t ur_groupnorm_ws_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(double); }
 size_t ur_groupnorm_ab_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(float); }
 
 int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int N, int HW,
-                      int C1, int C2, int G, float eps, int silu, void* ws, float* ab, ur_stream_t stream) {
+                      int C1, int C2, int G, float eps, int silu, void* ws, float* ab, const double* pre1, const double* pre2,
+                      ur_stream_t stream) {
   UR_REQUIRE(x && y && ws && ab, "null pointer");
   const int C = C1 + (x2 ? C2 : 0);
   UR_REQUIRE(C1 % 8 == 0 && (!x2 || C2 % 8 == 0) && G > 0 && C % G == 0 && N > 0 && HW > 0, "C%8, C%G");
@@ -231,11 +252,13 @@ int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma
     chunks[i] = (int)std::min<long long>(want, std::max(1, HW / (4 * R)));
     ppb[i] = (HW + chunks[i] - 1) / chunks[i];
     chunks[i] = (HW + ppb[i] - 1) / ppb[i];
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], stats, HW, cs[i], ppb[i], off[i], C,
-                       cvs[i]);
+    const double* pre = i == 0 ? pre1 : pre2;
+    if (!pre)
+      hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], stats, HW, cs[i], ppb[i], off[i],
+                         C, cvs[i]);
   }
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), (size_t)G * (2 * sizeof(double) + 2 * sizeof(float)), s, stats, ab,
-                     gamma, beta, HW, C, G, eps);
+                     gamma, beta, HW, C, G, eps, pre1, x2 ? pre2 : nullptr, C1);
   for (int i = 0; i < 2; ++i)
     if (cs[i] > 0)
       hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], (uint16_t*)y, ab, HW, cs[i], silu,

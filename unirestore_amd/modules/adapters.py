@@ -20,6 +20,11 @@ def _to_nhwc(x):
     return ops.nchw_to_nhwc(x.to(DEV))
 
 
+def _fresh():
+    """Operator-level entry (reference signature): start from a clean GroupNorm-sum arena."""
+    ops.arena().reset()
+
+
 class CSCEAdapter(nn.Module):
     """out = tuner(x + proj(cond)) + proj(cond) + x, as 3 GEMMs with the adds in their epilogues."""
 
@@ -31,9 +36,10 @@ class CSCEAdapter(nn.Module):
     def run(self, x, condition):
         s = ops.conv(condition, self.proj.packed(), residual=x)               # s = x + proj(cond)
         h = ops.conv(s, self.tuner["0"].packed(), act=UR_ACT_GELU)
-        return ops.conv(h, self.tuner["2"].packed(), residual=s)              # tuner(s) + s
+        return ops.conv(h, self.tuner["2"].packed(), residual=s, gn=True)     # tuner(s) + s (feeds a GroupNorm in the up path)
 
     def forward(self, x, condition):
+        _fresh()
         return ops.nhwc_to_nchw(self.run(_to_nhwc(x), _to_nhwc(condition)), c=x.shape[1])
 
 
@@ -75,9 +81,10 @@ class NAFBlock(nn.Module):
         x = ops.scale_channels(x, s)
         y = ops.conv(x, self.conv3.packed(scale=self.beta), residual=inp)      # inp + conv3(x)*beta (beta folded)
         x = ops.conv(self.norm2.run(y), self.conv4.packed(pair=True), act=UR_ACT_GATE)
-        return ops.conv(x, self.conv5.packed(scale=self.gamma), residual=y)    # y + conv5(x)*gamma
+        return ops.conv(x, self.conv5.packed(scale=self.gamma), residual=y, gn=True)    # y + conv5(x)*gamma
 
     def forward(self, inp):
+        _fresh()
         return ops.nhwc_to_nchw(self.run(_to_nhwc(inp)), c=inp.shape[1])
 
 
@@ -105,7 +112,7 @@ class AdaNAFV2(nn.Module):
     def run(self, inp):
         g = self.GROUPS
         wia, bia, wie, bie = self._vecs()
-        x = self.group_norm.run(ops.conv(inp, self.conv_in.packed()))
+        x = self.group_norm.run(ops.conv(inp, self.conv_in.packed(), gn=True))
         x = ops.conv(x, self.group_conv.packed(), act=UR_ACT_GELU)             # grouped 3x3 (+GELU)
         pooled = ops.avgpool(x)
         s_intra = ops.linear_f32(pooled, wia, bia, groups=g)                   # per-channel scale
@@ -115,6 +122,7 @@ class AdaNAFV2(nn.Module):
         return self.nafblock.run(ops.conv(x, self.pwconv.packed(), residual=inp))
 
     def forward(self, inp):
+        _fresh()
         return ops.nhwc_to_nchw(self.run(_to_nhwc(inp)), c=inp.shape[1])
 
 
@@ -125,6 +133,7 @@ class _Seq(nn.Sequential):
         return x
 
     def forward(self, x):
+        _fresh()
         return ops.nhwc_to_nchw(self.run(_to_nhwc(x)), c=x.shape[1])
 
 
@@ -166,7 +175,7 @@ class TaskFeatureAdapter(nn.Module):
         """x [B,h,w,c_out], skip [B,h,w,c_skip] bf16 NHWC; condition fp32 [B,T,D] -> (x', cond' or None)."""
         b, hh, ww, cs = skip.shape
         pc1, pc2 = self._fused()
-        sn = ops.group_norm(skip, None, None, cs, 1e-5)                        # InstanceNorm2d (no affine)
+        sn = ops.group_norm(skip, None, None, cs, 1e-5)                        # InstanceNorm2d (no affine); reuses fused sums
         h3 = ops.conv(sn, pc1, act=UR_ACT_GELU)
         pooled = torch.zeros((b, pc2.cout_out), dtype=torch.float32, device=skip.device)
         if (hh * ww) % 32 == 0:
@@ -178,7 +187,7 @@ class TaskFeatureAdapter(nn.Module):
         o = ops.linear_f32(upd.view(b, -1), wo, bo, UR_ACT_TANH)               # [B, D]
         hs = ops.scale_channels(ops.conv(skip, self.t_gate1.packed()), o)
         skip2 = ops.conv(hs, self.t_gate2.packed(), residual=skip)
-        x = ops.conv(x, self.conv_out.packed(), x2=skip2, residual=x)          # x + conv_out(cat[x, skip])
+        x = ops.conv(x, self.conv_out.packed(), x2=skip2, residual=x, gn=True)  # x + conv_out(cat[x, skip])
         new_cond = None
         if not self.last_layer:
             wp, bp = self.prompt_trans["0"].dev_f32()
@@ -186,6 +195,7 @@ class TaskFeatureAdapter(nn.Module):
         return x, new_cond
 
     def forward(self, x, skip, condition):
+        _fresh()
         y, c = self.run(_to_nhwc(x), _to_nhwc(skip), condition.to(DEV).float())
         return ops.nhwc_to_nchw(y, c=x.shape[1]), c
 

@@ -64,7 +64,7 @@ class Controller(nn.Module):
 
     def stem(self, z_bf16):
         """conv_in(z0) does not depend on t: computed once per image, reused by every step (controller.py:198)."""
-        return ops.conv(z_bf16, self.conv_in.packed())
+        return ops.conv(z_bf16, self.conv_in.packed(), gn=True)
 
     def run(self, stem, step):
         feats, h = [], stem
@@ -88,6 +88,7 @@ class Controller(nn.Module):
         if len(set(ts)) != 1:
             raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
         self.set_timesteps(ts[:1])
+        ops.arena().reset()
         out = self.run(self.stem(ops.nchw_to_nhwc(x.to(DEV))), 0)
         return {k: ops.nhwc_to_nchw(v) for k, v in out.items()}
 
@@ -128,7 +129,7 @@ class ControlledUNet(nn.Module):
     def run(self, zt_bf16, control, step):
         """zt_bf16 [B,h,w,8] (latent channels zero-padded), control {width: NHWC bf16} -> eps fp32 [B,h,w,8]."""
         u, ctx = self.unet, self._ctx()
-        h = ops.conv(zt_bf16, u.conv_in.packed())
+        h = ops.conv(zt_bf16, u.conv_in.packed(), gn=True)
         skips = [h]
         for blk in u.down_blocks:
             for i, res in enumerate(blk.resnets):
@@ -157,6 +158,7 @@ class ControlledUNet(nn.Module):
         if len(set(ts)) != 1:
             raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
         self.set_timesteps(ts[:1])
+        ops.arena().reset()
         ctl = {k: ops.nchw_to_nhwc(v.to(DEV)) for k, v in control.items()}
         eps = self.run(ops.nchw_to_nhwc(sample.to(DEV)), ctl, 0)
         return ops.nhwc_to_nchw(eps, c=self.unet.conv_out.out_channels)
@@ -190,7 +192,7 @@ class SkipConnectedAutoEncoder(nn.Module):
     def encode_run(self, images_dev: torch.Tensor, noise_nchw: torch.Tensor, enable_fr: bool):
         """images fp32 NCHW in [0,1] on device -> (z fp32 [B,h,w,8], z bf16, [3 NHWC bf16 skip features])."""
         enc, lat = self.vae.encoder, self.vae.latent_channels
-        h = ops.conv(ops.nchw_to_nhwc(images_dev, image=True), enc.conv_in.packed())            # x*2-1 fused in the layout pass
+        h = ops.conv(ops.nchw_to_nhwc(images_dev, image=True), enc.conv_in.packed(), gn=True)   # x*2-1 fused in the layout pass
         res = []
         for i, blk in enumerate(enc.down_blocks[:-1]):
             h = blk.run(h)
@@ -208,7 +210,7 @@ class SkipConnectedAutoEncoder(nn.Module):
         if task not in dec.task_prompts:
             raise KeyError(task)
         zb = ops.f32_to_bf16(z_f32, lat, mul=1.0 / self.vae.config.scaling_factor)
-        h = ops.conv(ops.conv(zb, self.vae.post_quant_conv.packed()), dec.conv_in.packed())
+        h = ops.conv(ops.conv(zb, self.vae.post_quant_conv.packed()), dec.conv_in.packed(), gn=True)
         h = dec.mid_block.run(h)
         b = z_f32.shape[0]
         key = ("cache", "prompt", task)
@@ -225,6 +227,7 @@ class SkipConnectedAutoEncoder(nn.Module):
     # ---- reference signatures ---------------------------------------------------------------------------------
     def encode(self, images, enable_fr: bool = False, noise=None):
         images = images.to(DEV).float()
+        ops.arena().reset()
         b, _, hh, ww = images.shape
         if noise is None:
             noise = torch.randn(b, self.vae.latent_channels, hh // 8, ww // 8, device=DEV)
@@ -232,6 +235,7 @@ class SkipConnectedAutoEncoder(nn.Module):
         return ops.nhwc_to_nchw(z, c=self.vae.latent_channels), [ops.nhwc_to_nchw(r) for r in res]
 
     def decode(self, latents, res_samples, task: str):
+        ops.arena().reset()
         z = ops.nchw_to_nhwc(latents.to(DEV)).float()
         return self.decode_run(z.contiguous(), [ops.nchw_to_nhwc(r.to(DEV)) for r in res_samples], task)
 
@@ -308,6 +312,7 @@ class DiffUIE(nn.Module):
     def _forward_device(self, images, task, n_vae, n_t):
         """images fp32 NCHW on device, padded to multiples of 64.  Returns (preds NCHW fp32, z0, zt) (NHWC fp32 latents)."""
         lat = self.ae.vae.latent_channels
+        ops.arena(images.device).reset()             # zero the fused GroupNorm sums of the previous forward (one fill)
         z0, z0b, mids = self.ae.encode_run(images, n_vae, enable_fr=self.fr_type is not None)
         zt = z0
         if self.control_type:
@@ -388,6 +393,7 @@ class DiffUIE(nn.Module):
         self.controller.set_timesteps(ts)
         self.base_model.set_timesteps(ts)
         self._tables_ready = False
+        ops.arena().reset()
         zb = ops.nchw_to_nhwc(latents.to(DEV))
         cb = ops.nchw_to_nhwc(conditions.to(DEV))
         outs = []

@@ -125,13 +125,13 @@ class ResnetBlock2D(nn.Module):
         bias = None
         if self.time_emb_proj is not None:
             bias = sample_bias if sample_bias is not None else self.tbias[step]
-        h = ops.conv(h, self.conv1.packed(), bias=bias)
+        h = ops.conv(h, self.conv1.packed(), bias=bias, gn=True)
         h = self.norm2.run(h, silu=True)
         if self.conv_shortcut is not None:
             sc = ops.conv(x, self.conv_shortcut.packed(), x2=x2)
         else:
             sc = x
-        return ops.conv(h, self.conv2.packed(), residual=sc)
+        return ops.conv(h, self.conv2.packed(), residual=sc, gn=True)
 
 
 class Downsample2D(nn.Module):
@@ -143,8 +143,8 @@ class Downsample2D(nn.Module):
     def run(self, x):
         n, h, w, _ = x.shape
         if self.padding == 0:          # VAE encoder: zero pad right/bottom by one, then stride-2 VALID conv
-            return ops.conv(x, self.conv.packed(), stride=2, pad=(0, 0), out_hw=(h // 2, w // 2))
-        return ops.conv(x, self.conv.packed(), stride=2, pad=(1, 1))
+            return ops.conv(x, self.conv.packed(), stride=2, pad=(0, 0), out_hw=(h // 2, w // 2), gn=True)
+        return ops.conv(x, self.conv.packed(), stride=2, pad=(1, 1), gn=True)
 
 
 class Upsample2D(nn.Module):
@@ -153,7 +153,7 @@ class Upsample2D(nn.Module):
         self.conv = Conv2d(c, c, 3, padding=1)
 
     def run(self, x):
-        return ops.conv(x, self.conv.packed(), upsample=True)      # nearest-2x gather fused into the loader
+        return ops.conv(x, self.conv.packed(), upsample=True, gn=True)      # nearest-2x gather fused into the loader
 
 
 # ----------------------------------------------------------------------------------------------- attention
@@ -172,7 +172,7 @@ def _fused_qkv(mod, names):
     return mod.__dict__[("cache", "qkv")]
 
 
-def self_attention(mod, h, heads, residual):
+def self_attention(mod, h, heads, residual, gn_kw={}):
     """h: [B,T,C] bf16 (already normalised).  One fused QKV GEMM (V written transposed), flash attention,
     output projection with the residual in its epilogue."""
     b, t, c = h.shape
@@ -186,7 +186,7 @@ def self_attention(mod, h, heads, residual):
                           bs_q=t * 3 * c, bs_k=t * 3 * c, bs_vt=c * ldvt, batch=b)
     else:
         o = attention_gemm(qk[:, :, :c], qk[:, :, c:2 * c], vt, heads, d, t)
-    return ops.linear(o, mod.to_out[0].packed(), residual=residual)
+    return ops.linear(o, mod.to_out[0].packed(), residual=residual, **gn_kw)
 
 
 def attention_gemm(q, k, vt, heads, d, t):
@@ -213,7 +213,8 @@ class AttentionBlock(nn.Module):
     def run(self, x):
         n, hh, ww, c = x.shape
         h = self.group_norm.run(x).view(n, hh * ww, c)
-        return self_attention(self, h, self.heads, x.view(n, hh * ww, c)).view(n, hh, ww, c)
+        o = self_attention(self, h, self.heads, x.view(n, hh * ww, c), gn_kw=dict(gn=True, gn_hw=(n, hh * ww)))
+        return ops.carry(o, o.view(n, hh, ww, c))
 
 
 class CrossAttention(nn.Module):
@@ -289,7 +290,8 @@ class Transformer2DModel(nn.Module):
         n, hh, ww, c = x.shape
         h = ops.linear(self.norm.run(x).view(n, hh * ww, c), self.proj_in.packed())
         h = self.transformer_blocks[0].run(h, ctx)
-        return ops.linear(h, self.proj_out.packed(), residual=x.view(n, hh * ww, c)).view(n, hh, ww, c)
+        o = ops.linear(h, self.proj_out.packed(), residual=x.view(n, hh * ww, c), gn=True, gn_hw=(n, hh * ww))
+        return ops.carry(o, o.view(n, hh, ww, c))
 
 
 # ----------------------------------------------------------------------------------------------- blocks

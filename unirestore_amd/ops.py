@@ -3,6 +3,7 @@
 Activations are NHWC bf16 tensors ([N,H,W,C] or [rows, C]); C is always a multiple of 8 (thin tensors such as
 images / latents are zero-padded to 8 channels).  PyTorch only owns memory and the stream here.
 """
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -44,6 +45,52 @@ def _gn_ab(dev, nbytes) -> torch.Tensor:
     return _ws[key]
 
 
+class StatsArena:
+    """Bump allocator for the fp64 GroupNorm channel sums that conv epilogues produce (ur_conv_desc.gn_stats).
+    One zero-fill of the used part per forward (`reset`) replaces a zero-fill per GroupNorm."""
+
+    def __init__(self, dev, n_doubles=48 << 20):
+        self.buf = torch.zeros(n_doubles, dtype=torch.float64, device=dev)
+        self.off = 0
+        self.high = 0
+
+    def reset(self):
+        if self.high:
+            self.buf[:self.high].zero_()
+        self.off = 0
+
+    def alloc(self, n):
+        n = round_up(n, 2)
+        assert self.off + n <= self.buf.numel(), "GroupNorm stats arena exhausted"
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        self.high = max(self.high, self.off)
+        return v
+
+
+_arena = {}
+
+
+def arena(dev=None) -> StatsArena:
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else dev
+    if dev not in _arena:
+        _arena[dev] = StatsArena(dev)
+    return _arena[dev]
+
+
+def gn_of(t):
+    """Fused GroupNorm sums attached to tensor `t` by its producer (or None)."""
+    return getattr(t, "_gn", None)
+
+
+def carry(src, dst):
+    """Propagate the producer's statistics across a reshape / view."""
+    g = getattr(src, "_gn", None)
+    if g is not None:
+        dst._gn = g
+    return dst
+
+
 def round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -60,9 +107,10 @@ class PackedConv:
     k: int            # kernel size (1 or 3)
     groups: int = 1
     pair: bool = False
+    kcm: bool = False  # K order (64-ch chunk, tap, ch) instead of (tap, ch): consecutive K tiles re-read the same pixels (L2)
 
 
-def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=False, groups=1, cin_pad=None) -> PackedConv:
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=False, groups=1, cin_pad=None, c1=None) -> PackedConv:
     """weight: [Cout, Cin/groups, k, k] (nn.Conv2d) or [N, K] (nn.Linear), fp32 master on any device.
     The repack (OIHW -> O,kh,kw,I; zero padding; a|g interleave; bf16 cast) runs on `dev` with torch copies."""
     w = weight.detach().to(dev, torch.float32)
@@ -91,14 +139,19 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=F
         wp = wp[idx]
         b = b[idx] if b is not None else None
         cout_out = half
+    # chunk-major K for 3x3 kernels: [Cout][kh*kw][Cin/64][64] -> [Cout][Cin/64][kh*kw][64]; c1 = channels of the first
+    # source when the input is a virtual concat (chunks must not straddle it)
+    kcm = kh == 3 and groups == 1 and cin_p % 64 == 0 and (c1 is None or c1 % 64 == 0) and os.environ.get("UR_KCM", "1") == "1"
+    if kcm:
+        wp = wp.reshape(cout_p, kh * kw, cin_p // 64, 64).permute(0, 2, 1, 3)
     return PackedConv(wp.reshape(cout_p, kh * kw * cin_p).to(BF16).contiguous(),
-                      None if b is None else b.contiguous(), cin_p, cout_p, cout_out, kh, groups, pair)
+                      None if b is None else b.contiguous(), cin_p, cout_p, cout_out, kh, groups, pair, kcm)
 
 
 # ------------------------------------------------------------------------------------------------ conv / gemm
 def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, act=UR_ACT_NONE, stride=1, pad=None,
          out_hw=None, upsample=False, out_f32=False, out_scale=1.0, out=None, yt=None, n_split=0, t_rows=0,
-         colsum=None, colsum_scale=1.0):
+         colsum=None, colsum_scale=1.0, gn=False):
     """x: [N,H,W,C1] bf16 (x2 optional [N,H,W,C2], virtual concat).  Returns [N,OH,OW,cout_out]."""
     assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
     n, h, w_, c1 = x.shape
@@ -121,6 +174,10 @@ def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, 
     if bias is not None and bias.dim() == 2 and bias.shape[0] > 1:
         d.bias_img_stride = bias.shape[1]
     d.residual, d.y, d.yt, d.colsum = _ptr(residual), _ptr(out), _ptr(yt), _ptr(colsum)
+    stats = None
+    if gn:      # the consumer of `out` is a GroupNorm: have the epilogue (or a fallback pass) leave its channel sums
+        stats = arena(x.device).alloc(n * co_total * 2)
+        d.gn_stats = stats.data_ptr()
     ws = workspace(x.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.N, d.H, d.W = n, h, w_
@@ -133,6 +190,8 @@ def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, 
     d.stride, d.pad_t, d.pad_l, d.OH, d.OW = stride, pad[0], pad[1], oh, ow
     d.upsample2x, d.act, d.out_f32 = int(upsample), act, int(out_f32)
     d.n_split, d.t_rows = n_split, t_rows
+    d.k_chunk_major = int(pc.kcm and (c2 == 0 or c1 % 64 == 0))
+    assert not pc.kcm or d.k_chunk_major, "chunk-major weights need a 64-aligned concat boundary"
     d.t_ld = yt.shape[-1] if yt is not None else 0
     d.out_scale, d.colsum_scale = out_scale, colsum_scale
     d.nbatch = g
@@ -140,6 +199,8 @@ def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, 
         d.bs_x, d.bs_w, d.bs_bias, d.bs_y = c1 // g, (pc.cout // g) * pc.w.shape[1], pc.cout // g, pc.cout_out // g
         d.bs_r = pc.cout_out // g
     check(lib.ur_conv2d_nhwc(d, _stream()))
+    if stats is not None:
+        out._gn = stats
     return out
 
 
@@ -150,8 +211,14 @@ def linear(x: torch.Tensor, pc: PackedConv, **kw):
     res = kw.pop("residual", None)
     if res is not None:
         res = res.reshape(1, 1, rows, res.shape[-1])
-    y = conv(x.reshape(1, 1, rows, shp[-1]), pc, residual=res, **kw)
-    return None if y is None else y.reshape(*shp[:-1], y.shape[-1])
+    gn = kw.pop("gn", False)
+    gn_hw = kw.pop("gn_hw", None)       # (N, HW): how the rows split into images for the fused GroupNorm sums
+    if gn:
+        n_img, hw = gn_hw
+        y = conv(x.reshape(n_img, 1, hw, shp[-1]), pc, residual=None if res is None else res.reshape(n_img, 1, hw, -1), gn=True, **kw)
+    else:
+        y = conv(x.reshape(1, 1, rows, shp[-1]), pc, residual=res, **kw)
+    return None if y is None else carry(y, y.reshape(*shp[:-1], y.shape[-1]))
 
 
 def bmm_nt(a: torch.Tensor, bmat: torch.Tensor, *, out_f32=False, out_scale=1.0):
@@ -173,7 +240,7 @@ def bmm_nt(a: torch.Tensor, bmat: torch.Tensor, *, out_f32=False, out_scale=1.0)
 
 
 # ------------------------------------------------------------------------------------------------ norms
-def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu=False, x2=None):
+def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu=False, x2=None, use_pre=True):
     """x: [N,H,W,C1] bf16 (+ optional x2 [N,H,W,C2], normalised as one concatenated tensor) -> [N,H,W,C1+C2].
     gamma/beta fp32 [C] or None (InstanceNorm when groups == C)."""
     assert x.dtype == BF16 and x.is_contiguous()
@@ -183,8 +250,10 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu=False
     out = torch.empty((*x.shape[:-1], c1 + c2), dtype=BF16, device=x.device)
     ws = _gn_ws(x.device, lib.ur_groupnorm_ws_bytes(n, c1 + c2))
     ab = _gn_ab(x.device, lib.ur_groupnorm_ab_bytes(n, c1 + c2))
+    pre1 = gn_of(x) if use_pre else None
+    pre2 = gn_of(x2) if (use_pre and x2 is not None) else None
     check(lib.ur_groupnorm_nhwc(x.data_ptr(), _ptr(x2), out.data_ptr(), _ptr(gamma), _ptr(beta), n, hw, c1, c2, groups, eps,
-                                int(silu), ws.data_ptr(), ab.data_ptr(), _stream()))
+                                int(silu), ws.data_ptr(), ab.data_ptr(), _ptr(pre1), _ptr(pre2), _stream()))
     return out
 
 
