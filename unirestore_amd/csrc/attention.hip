@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[f * 16 + r] = sacc[f][r] * p.scale_log2e;
+      for (int r = 0; r < 16; ++r) s[f * 16 + r] = sacc[f][r];
     if ((t + 1) * 64 > p.Tk) {
 #pragma unroll
       for (int f = 0; f < 2; ++f)
@@ -135,24 +135,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
           if (key >= p.Tk) s[f * 16 + r] = -INFINITY;
         }
     }
+    // online softmax in the exp2 domain on RAW scores: p = exp2(c*s - c*m), c = scale*log2(e) folded into one FMA.
     float mx = s[0];
 #pragma unroll
     for (int i = 1; i < 32; ++i) mx = fmaxf(mx, s[i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float c = p.scale_log2e;
+    // deferred rescale: while no row's maximum grew by more than 2^8 (in the exp2 domain) keep the old reference
+    // maximum - P is then bounded by 256 instead of 1 (harmless in bf16/fp32) and the O / l rescale is skipped.
+    if (!__all((mx - m_run) * c <= 8.0f)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int f = 0; f < DF; ++f)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[f][e] *= alpha;
+    }
+    const float mc = m_run * c;
     float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-      s[i] = __builtin_amdgcn_exp2f(s[i] - m_new);
+      s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], c, -mc));
       psum += s[i];
     }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int f = 0; f < DF; ++f)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[f][e] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T P^T : 4 k-steps of 16 keys; P^T fragment = 8 consecutive accumulator registers ----
 #pragma unroll
