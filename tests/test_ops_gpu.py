@@ -271,3 +271,21 @@ def test_conv_fused_groupnorm_stats(ops, n, cin, cout, h, w, k):
     out = ops.group_norm(y, ga.cuda(), be.cuda(), 32, 1e-5, True)
     ref = F.silu(F.group_norm(_nchw(y), 32, ga, be, eps=1e-5))
     assert rel_l2(_nchw(out), ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,ups,res", [(2, 64, 128, 16, 32, False, False), (1, 320, 320, 32, 32, False, True),
+                                                    (8, 128, 160, 8, 64, False, False), (2, 192, 256, 8, 16, True, True)])
+def test_conv_halo_tile_path(ops, n, cin, cout, h, w, ups, res):
+    """3x3 / stride 1 / pad 1 shapes that take the LDS halo-tile kernel (8x32 output patches), incl. fused upsample."""
+    g = _gen(cin + cout + h)
+    x = _rb(torch.randn(n, cin, h, w, generator=g)); wt = _rb(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(xin, wt, b, padding=1)
+    r = _rb(torch.randn(ref.shape, generator=g)) if res else None
+    ops.arena().reset()
+    y = ops.conv(_nhwc(x), ops.pack_conv(wt, b, "cuda"), upsample=ups, residual=None if r is None else _nhwc(r), gn=True)
+    ref = ref + r if res else ref
+    assert rel_l2(_nchw(y), ref) < TOL_BF16
+    st = ops.gn_of(y).view(n, cout, 2).cpu()
+    assert rel_l2(st[..., 0], _nchw(y).double().sum((2, 3))) < 1e-5

@@ -31,10 +31,17 @@ struct ConvK {
   long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r, bias_img;
   size_t ws_bytes_;
   int dbg, gn_fused, staged_ok_;
+  int patch_tw, patch_m0_unused;   // >0: tile rows are an (BM/patch_tw) x patch_tw pixel patch of one image (halo kernel)
   int kcm;   // 1: K runs (64-channel chunk, tap, channel) - the 9 taps of a chunk are consecutive K tiles (L2 reuse)
 };
 
 __device__ __forceinline__ bool is_pair_act(int act) { return act == UR_ACT_GEGLU || act == UR_ACT_GATE; }
+
+// tile row r -> global output row.  Linear tiles: m0 + r.  Patch tiles (halo kernel): m0 is the patch's first pixel and
+// rows run (py, px) over a patch_tw-wide window of an OW-wide image.
+__device__ __forceinline__ int tile_row_to_m(const ConvK& p, int m0, int r) {
+  return p.patch_tw ? m0 + (r / p.patch_tw) * p.OW + (r % p.patch_tw) : m0 + r;
+}
 
 // Final stage for 4 consecutive output channels [co, co+4) of pixel row m (values already activated/scaled).
 __device__ __forceinline__ void epi_residual(const ConvK& p, int gb, int m, int co, float v[4]) {
@@ -104,7 +111,8 @@ __device__ __forceinline__ int epi_act(const ConvK& p, int gb, int m, int co_in,
 // (row, chunk) split is a multiply-shift, and LDS rows (stride SROW, 8-byte aligned) are touched with ds_*_b64.
 // Loads are issued in batches of U before any is consumed (latency paid once per batch, not once per chunk).
 template <int BM, int NC, int NT, int SROW, bool LOAD>
-__device__ __forceinline__ void tile_copy(uint16_t* g, long long ld, unsigned char* smem, int m0, int M, int c0, int cmax) {
+__device__ __forceinline__ void tile_copy(const ConvK& p, uint16_t* g, long long ld, unsigned char* smem, int m0, int M, int c0,
+                                          int cmax) {
   constexpr int Q = NC / 8;                               // 16-byte chunks per row
   constexpr int TOT = BM * Q, U = 5;
   for (int i0 = threadIdx.x; i0 < TOT; i0 += NT * U) {
@@ -116,8 +124,9 @@ __device__ __forceinline__ void tile_copy(uint16_t* g, long long ld, unsigned ch
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * NT;
       const int r = i / Q, c = (i - r * Q) * 8;
-      ok[u] = i < TOT && m0 + r < M && c < cmax;
-      gp[u] = g + (long long)(m0 + (ok[u] ? r : 0)) * ld + c0 + (ok[u] ? c : 0);
+      const int m = tile_row_to_m(p, m0, i < TOT ? r : 0);
+      ok[u] = i < TOT && m < M && c < cmax;
+      gp[u] = g + (long long)(ok[u] ? m : m0) * ld + c0 + (ok[u] ? c : 0);
       lp[u] = reinterpret_cast<uint2*>(smem + (ok[u] ? r * SROW + c * 2 : 0));
       if (LOAD) v[u] = *reinterpret_cast<const uint4*>(gp[u]);
       else { const uint2 a = lp[u][0], b = lp[u][1]; v[u] = make_uint4(a.x, a.y, b.x, b.y); }
@@ -224,8 +233,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
     for (int i = threadIdx.x; i < 2 * BN; i += NT) facc[i] = 0.f;
   if (p.res) {                                            // residual tile -> LDS, coalesced
     uint16_t* rb = const_cast<uint16_t*>(p.res) + gb * p.bs_r;
-    if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, true>(rb, p.ldr, smem, m0, p.M, c0, cmax);
-    else tile_copy<BM, BN, NT, SROW, true>(rb, p.ldr, smem, m0, p.M, c0, cmax);
+    if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, true>(p, rb, p.ldr, smem, m0, p.M, c0, cmax);
+    else tile_copy<BM, BN, NT, SROW, true>(p, rb, p.ldr, smem, m0, p.M, c0, cmax);
   }
   __syncthreads();
   const bool has_res = p.res != nullptr;
@@ -260,9 +269,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-        const bool ok = col_ok && m0 + lm < p.M;
+        const int mg = tile_row_to_m(p, m0, lm);
+        const bool ok = col_ok && mg < p.M;
         if (p.yt && co >= p.n_split) {                                   // transposed columns (V^T) go out directly
-          if (ok) epi_store(p, gb, m0 + lm, co, v);
+          if (ok) epi_store(p, gb, mg, co, v);
           continue;
         }
         uint2* sp = reinterpret_cast<uint2*>(smem + lm * SROW + lco * 2);
@@ -284,7 +294,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
     const int CP = ncols >> 1, NG = NT / CP, RGN = (BM + NG - 1) / NG;
     const int cp = threadIdx.x % CP, g = threadIdx.x / CP;
     if (g < NG && cp * 2 < cmax) {
-      const int r0 = g * RGN, r1 = min(min(BM, r0 + RGN), p.M - m0);
+      const int r0 = g * RGN, r1 = p.patch_tw ? min(BM, r0 + RGN) : min(min(BM, r0 + RGN), p.M - m0);
       float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
       for (int r = r0; r < r1; ++r) {
         const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * SROW + cp * 4);
@@ -303,8 +313,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
     }
   }
   uint16_t* yb = reinterpret_cast<uint16_t*>(p.y) + gb * p.bs_y;
-  if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, false>(yb, p.ldy, smem, m0, p.M, c0, cmax);
-  else tile_copy<BM, BN, NT, SROW, false>(yb, p.ldy, smem, m0, p.M, c0, cmax);
+  if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, false>(p, yb, p.ldy, smem, m0, p.M, c0, cmax);
+  else tile_copy<BM, BN, NT, SROW, false>(p, yb, p.ldy, smem, m0, p.M, c0, cmax);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -940,8 +950,204 @@ int launch_ws(ConvK& k, hipStream_t s) {
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
+
+// =====================================================================================================================
+// Halo-tile 3x3 convolution (stride 1, pad 1, optional nearest-2x upsampled input).
+// The L2 -> CU ingest path, not the MFMA pipe, bounds the implicit GEMM (about 13 B/clk/CU: ~8 KB in flight against
+// ~600 cycles of L2 latency; LDS-DMA does not allocate in L1), and the tap-major loaders re-fetch every input pixel
+// 9 times.  Here a workgroup owns an 8 x 32 pixel output patch of ONE image: per 64-channel chunk the (8+2) x (32+2)
+// input patch is DMA'd into LDS once (double-buffered across chunks, spread over the first six taps of the previous
+// chunk) and the nine taps read their B fragments out of it at a constant row offset; only the weight tile streams per
+// K tile (3-stage ring).  Ingest per K tile drops from (256+BN)*128 B to ~BN*128 B + 5 KB.
+// A fragment is one 32-pixel patch row, so its LDS rows are consecutive for every tap and the (row>>1)&7 slot swizzle
+// stays conflict-free (tools/lds_conflicts.py model; a 16x16 patch would be 2-way conflicted on every tap).
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
+  constexpr int BM = 256, TH = 8, TW = 32, PW = TW + 2, HPIX = (TH + 2) * PW;       // 340 halo pixels
+  constexpr int HPIECES = 48, HBYTES = HPIECES * 1024;   // 6 tap slots x 8 waves; pieces >= 43 are never read (zero fill)
+  constexpr int WBYTES = BN * 128, WPIECES = BN / 8, WPW = (WPIECES + 7) / 8;         // weight pieces per wave per tile
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = 512;
+  static_assert(WM * WN == 8 && WTM % 32 == 0 && WTN % 32 == 0, "8 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const hbuf = smem;                      // 2 halo patches
+  unsigned char* const wring = smem + 2 * HBYTES;        // 3 weight tiles
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid % WM, wn = wid / WM;
+  int id = blockIdx.x;
+  {
+    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = id % p.tiles_n, tmi = id / p.tiles_n;
+  const int tiles_x = p.OW / TW, tiles_y = p.OH / TH;
+  const int tx = tmi % tiles_x, ty = (tmi / tiles_x) % tiles_y, img = tmi / (tiles_x * tiles_y);
+  const int n0 = tn * BN;
+  const int m0 = img * p.OHW + ty * TH * p.OW + tx * TW;         // first output pixel of the patch
+
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const uint16_t* __restrict__ X1 = p.x;
+  const uint16_t* __restrict__ X2 = p.x2;
+  const uint16_t* __restrict__ Wt = p.w;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+  const int lr = lane >> 3, ps = lane & 7;
+  // Every piece this wave issues has index == wid (mod 8), so its rows share one parity pattern and the lane's logical
+  // 16-byte K chunk is the same for all of them: physical slot ps holds chunk ps ^ ((row>>1)&7), row = 8*piece + lr.
+  const int chunk = ps ^ ((((wid & 1) << 2) + (lr >> 1)) & 7);
+
+  // input-pixel index of this lane for the six halo pieces (tap slots 0..5) this wave issues per chunk; -1 = zero fill
+  int hpix[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    const int hr = (t * 8 + wid) * 8 + lr;
+    const int hy = hr / PW, hx = hr - hy * PW;
+    int iy = ty * TH - 1 + hy, ix = tx * TW - 1 + hx;               // coordinates in the (possibly upsampled) input
+    const bool v = hr < HPIX && (unsigned)iy < (unsigned)p.OH && (unsigned)ix < (unsigned)p.OW;
+    if (p.ups) { iy >>= 1; ix >>= 1; }
+    hpix[t] = v ? (img * p.H + iy) * p.W + ix : -1;
+  }
+  int woff[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int qq = (wid + 8 * i < WPIECES) ? wid + 8 * i : wid;       // surplus slot: repeat this wave's first piece
+    const int row = n0 + qq * 8 + lr;
+    woff[i] = row < p.Cout ? row * p.ldw : -1;
+  }
+  const int nk = p.nk, nchunk = nk / 9;
+
+  auto issue_w = [&](int kt) {
+    unsigned char* st = wring + (kt % 3) * WBYTES;
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      const int qq = (wid + 8 * i < WPIECES) ? wid + 8 * i : wid;
+      const uint16_t* g = woff[i] >= 0 ? Wt + woff[i] + kt * 64 + chunk * 8 : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + qq * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_h = [&](int c, int t) {                                // halo piece (t*8 + wid) of chunk c
+    const int q = t * 8 + wid;
+    int cc = c * 64 + chunk * 8;
+    const uint16_t* src = X1;
+    int ld = p.ldx;
+    if (cc >= p.C1) { src = X2; ld = p.ldx2; cc -= p.C1; }
+    const uint16_t* g = hpix[t] >= 0 ? src + hpix[t] * ld + cc : zero;
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(hbuf + (c & 1) * HBYTES + q * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  // ---- prologue: whole halo of chunk 0, weight tiles 0 and 1 ------------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < 6; ++t) issue_h(0, t);
+  issue_w(0);
+  if (nk > 1) {
+    issue_w(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0, c = 0, tap = 0; kt < nk; ++kt) {
+    const bool more_w = kt + 2 < nk;
+    const bool more_h = tap < 6 && c + 1 < nchunk;
+    if (more_w) issue_w(kt + 2);
+    if (more_h) {
+      switch (tap) {                                                 // hpix[] must be indexed statically
+        case 0: issue_h(c + 1, 0); break;
+        case 1: issue_h(c + 1, 1); break;
+        case 2: issue_h(c + 1, 2); break;
+        case 3: issue_h(c + 1, 3); break;
+        case 4: issue_h(c + 1, 4); break;
+        default: issue_h(c + 1, 5); break;
+      }
+    }
+    // ---- MFMAs of K tile kt: B fragments = patch rows shifted by the tap, A fragments = weight tile -------------------
+    {
+      const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+      const unsigned char* hb = hbuf + (c & 1) * HBYTES;
+      const unsigned char* wsm = wring + (kt % 3) * WBYTES;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int slot = ks * 2 + fhalf;
+        bf16x8 bfr[FM], afr[FN];
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+          const int hrow = (wm * FM + b + dy) * PW + dx + frow;
+          bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+          const int row = wn * WTN + a * 32 + frow;
+          afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < FM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
+    if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
+    else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+    else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (++tap == 9) { tap = 0; ++c; }
+  }
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem);
+}
+
+template <int BN, int WM, int WN>
+int launch_halo(ConvK& k, hipStream_t s) {
+  constexpr int HBYTES = 48 * 1024;
+  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = 256 * (BN * 2 + 8) + 3 * BN * 4;
+  constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  k.tiles_m = k.N * (k.OH / 8) * (k.OW / 32);
+  k.tiles_n = (k.Cout + BN - 1) / BN;
+  k.splitk = 1;
+  k.nk_per_split = k.nk;
+  k.patch_tw = 32;
+  k.gn_fused = k.gn_stats != nullptr;                      // a patch never leaves its image
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN>), dim3(k.tiles_m * k.tiles_n), dim3(512), lds, s, k);
+  return ur::check_launch("ur_conv2d_nhwc");
+}
+
 int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
-  static const bool use_v1 = getenv("UR_IGEMM_V1") != nullptr;
+  k.patch_tw = 0;
+  static const bool no_halo = getenv("UR_IGEMM_NOHALO") != nullptr;
+  if (!no_halo && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && k.staged_ok_ && !pair && k.nbatch == 1 &&
+      k.OW % 32 == 0 && k.OH % 8 == 0 && k.OH == (k.ups ? 2 * k.H : k.H) && k.OW == (k.ups ? 2 * k.W : k.W) && !k.yt) {
+    const bool n160h = k.Cout % 160 == 0 && k.Cout % 128 != 0;
+    const long long tiles = (long long)k.N * (k.OH / 8) * (k.OW / 32) * ((k.Cout + (n160h ? 159 : 127)) / (n160h ? 160 : 128));
+    if (tiles >= 128 && (n160h || k.Cout % 128 == 0)) {
+      if (n160h) return launch_halo<160, 8, 1>(k, s);
+      return launch_halo<128, 4, 2>(k, s);
+    }
+  }
+  static const int exp_mode = getenv("UR_IGEMM_EXP") ? atoi(getenv("UR_IGEMM_EXP")) : 0;
+  if (exp_mode && k.KH == 1 && k.nk <= exp_mode && !pair && k.Cout > 64) {      // short-K GEMMs: 2 workgroups per CU
+    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_glds<128, 160, 4, 1, 2>(k, s, 0);
+    return launch_glds<128, 128, 2, 2, 2>(k, s, 0);
+  }
+  static const bool force_v1 = getenv("UR_IGEMM_V1") != nullptr;
+  // short-K GEMMs (<= 10 K tiles: per-workgroup prologue/epilogue latency dominates): 128-row tiles, 2 workgroups per CU
+  const bool use_v1 = force_v1 || (k.KH == 1 && k.nk <= 10);
   if (use_v1) {
     if (pair) return launch_cfg<128, 128, 2, 2>(k, s);  // a|g 32-row blocks must sit in one wave tile
     if (k.Cout <= 32) return launch_cfg<256, 32, 4, 1>(k, s);
@@ -972,11 +1178,6 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
     }
     if (n160) return launch_ws<256, 160, 8, 1, 4>(k, s);
     return launch_ws<256, 128, 4, 2, 4>(k, s);
-  }
-  static const int exp_mode = getenv("UR_IGEMM_EXP") ? atoi(getenv("UR_IGEMM_EXP")) : 0;
-  if (exp_mode == 1 && !pair) {
-    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_glds<128, 160, 4, 1, 2>(k, s, 0);
-    return launch_glds<128, 128, 2, 2, 2>(k, s, 0);
   }
   static const int small_mode = getenv("UR_IGEMM_SMALL") ? atoi(getenv("UR_IGEMM_SMALL")) : 2;
   if (small_mode == 1) return launch_glds<128, 128, 2, 2, 2>(k, s, 400);
