@@ -12,7 +12,10 @@
 //     ds_write_b128 staging pattern and the ds_read_b128 fragment pattern of 32-row MFMA operands.
 //   * zero padding, stride, nearest-2x upsample and channel concat are address arithmetic in the loader.
 //   * block id -> tile map is XCD-aware (blocks that share an activation tile land on one XCD's L2).
+#include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <string>
 
 #include "common.h"
 
@@ -1231,7 +1234,16 @@ extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * k.M * (double)k.Cout * k.Ktot * k.nbatch;
   const double bytes = 2.0 * ((double)k.M * k.Cin + (double)k.Cout * k.Ktot + (double)k.M * k.Cout) * k.nbatch;
-  ur::ProfScope prof(d->KH == 3 ? "conv3x3_igemm" : "gemm1x1_igemm", flops, bytes, s);
+  const char* fam = d->KH == 3 ? "conv3x3_igemm" : "gemm1x1_igemm";
+  static const bool prof_shapes = getenv("UR_PROF_SHAPES") != nullptr;
+  if (prof_shapes) {           // per-shape families for offline analysis (interned strings keep the pointers stable)
+    static std::map<std::string, int> interned;
+    char buf[128];
+    snprintf(buf, sizeof buf, "%s M%d N%d K%d s%d u%d b%d a%d", d->KH == 3 ? "c3" : "g1", k.M, k.Cout, k.Ktot, d->stride, d->upsample2x,
+             k.nbatch, d->act);
+    fam = interned.emplace(buf, 0).first->first.c_str();
+  }
+  ur::ProfScope prof(fam, flops, bytes, s);
   const int rc = dispatch_conv(k, s, pair);
   if (rc != UR_OK) return rc;
   if (k.gn_stats && !k.gn_fused) {   // this launch could not fuse the statistics: one extra pass over the output

@@ -391,6 +391,6 @@ def profile_enable(on: bool):
 def profile_report() -> dict:
     import ctypes
     import json
-    buf = ctypes.create_string_buffer(1 << 16)
+    buf = ctypes.create_string_buffer(1 << 20)
     check(lib.ur_profile_report(buf, len(buf)))
     return json.loads(buf.value.decode())
