@@ -117,6 +117,63 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
   }
 }
 
+// ---- GroupNorm apply with the finalize folded in (all sources carry producer-side sums) -------------------------------
+// Each block rebuilds mean / rstd only for the groups its <=256-channel slab touches: cooperative fp64 LDS reduction over
+// those groups' channel sums, then the same streaming pass as gn_apply_kernel.  Saves one launch per GroupNorm.
+__global__ __launch_bounds__(256) void gn_apply_fused_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                             const double* __restrict__ pre1, const double* __restrict__ pre2,
+                                                             int C1, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int HW, int C, int silu,
+                                                             int pix_per_block, int c_off, int C_total, int G, float eps, int CVS) {
+  __shared__ double gs[2][264];
+  __shared__ float gm[2][264];
+  const int n = blockIdx.y, t = threadIdx.x;
+  const int CV = C >> 3, R = 256 / CVS, cpg = C_total / G;
+  const int cb = c_off + blockIdx.z * CVS * 8, ce = min(cb + CVS * 8, c_off + C);       // this slab in the C_total domain
+  const int g_lo = cb / cpg, g_hi = (ce - 1) / cpg, ng = g_hi - g_lo + 1;
+  for (int g = t; g < ng; g += 256) { gs[0][g] = 0.0; gs[1][g] = 0.0; }
+  __syncthreads();
+  const int C2 = C_total - C1;
+  for (int c = g_lo * cpg + t; c < (g_hi + 1) * cpg; c += 256) {
+    const double* src = c < C1 ? pre1 + ((long long)n * C1 + c) * 2 : pre2 + ((long long)n * C2 + (c - C1)) * 2;
+    atomicAdd(&gs[0][c / cpg - g_lo], src[0]);
+    atomicAdd(&gs[1][c / cpg - g_lo], src[1]);
+  }
+  __syncthreads();
+  for (int g = t; g < ng; g += 256) {
+    const double cnt = (double)cpg * HW, mean = gs[0][g] / cnt;
+    double var = gs[1][g] / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    gm[0][g] = (float)mean;
+    gm[1][g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int r = t / CVS, v = blockIdx.z * CVS + (t - r * CVS);
+  if (r >= R || v >= CV) return;
+  float a[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c_off + v * 8 + e, g = c / cpg - g_lo;
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    a[e] = gm[1][g] * ga;
+    b[e] = be - gm[0][g] * a[e];
+  }
+  const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+  const uint16_t* xi = x + (long long)n * HW * C + v * 8;
+  uint16_t* yo = y + (long long)n * HW * C_total + c_off + v * 8;
+  for (int p = p_begin + r; p < p_end; p += R) {
+    uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C);
+    float f[8];
+    unpack8(raw, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float o = f[e] * a[e] + b[e];
+      f[e] = silu ? silu_f(o) : o;
+    }
+    *reinterpret_cast<uint4*>(yo + (long long)p * C_total) = pack8(f);
+  }
+}
+
 // ---- LayerNorm over C: one wave per row, R rows per wave in flight, exact two-pass variance in registers --------
 template <int VPL, int R>  // vectors (8 elems) per lane, rows batched per wave
 __global__ __launch_bounds__(256) void ln_rows_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
@@ -256,6 +313,15 @@ int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma
     if (!pre)
       hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], stats, HW, cs[i], ppb[i], off[i],
                          C, cvs[i]);
+  }
+  const bool all_pre = pre1 && (!x2 || pre2);
+  const int cpg = C / G;
+  if (all_pre && (256 / cpg + 2) <= 264) {
+    for (int i = 0; i < 2; ++i)
+      if (cs[i] > 0)
+        hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], (uint16_t*)y, pre1,
+                           x2 ? pre2 : nullptr, C1, gamma, beta, HW, cs[i], silu, ppb[i], off[i], C, G, eps, cvs[i]);
+    return ur::check_launch("ur_groupnorm_nhwc");
   }
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), (size_t)G * (2 * sizeof(double) + 2 * sizeof(float)), s, stats, ab,
                      gamma, beta, HW, C, G, eps, pre1, x2 ? pre2 : nullptr, C1);
