@@ -23,7 +23,10 @@ struct AttnP {
 __device__ __forceinline__ int swap23(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+#ifndef UR_ATTN_WAVES
+#define UR_ATTN_WAVES 3
+#endif
+__global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_kernel(const AttnP p) {
   constexpr int KROW = D * 2;                 // bytes per K row in LDS
   constexpr int KSLOTS = KROW / 16;           // 16-B slots per K row (8 or 16)
   constexpr int KT = 64 * KROW;               // K tile bytes

@@ -49,27 +49,32 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restri
   }
 }
 
-// ---- mean over HW -> fp32 [N][C] (atomics into a pre-zeroed output) ---------------------------------
+// ---- mean over HW -> fp32 [N][C]: (pixel chunk, image, channel slab) grid, LDS combine, one atomic per channel/block ---
 __global__ __launch_bounds__(256) void avgpool_kernel(const uint16_t* __restrict__ x, float* __restrict__ out, int HW, int C,
-                                                      int pix_per_block, float inv) {
-  const int n = blockIdx.y, t = threadIdx.x, CV = C >> 3;
+                                                      int pix_per_block, float inv, int CVS) {
+  __shared__ float lds[256];
+  const int n = blockIdx.y, t = threadIdx.x, CV = C >> 3, R = 256 / CVS;
+  const int r = t / CVS, vl = t - r * CVS, v = blockIdx.z * CVS + vl;
   const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
-  const uint16_t* xi = x + (long long)n * HW * C;
-  const int R = max(1, 256 / CV);
-  for (int v0 = 0; v0 < CV; v0 += 256) {
-    int r = 0, v = v0 + t;
-    if (CV <= 256) { r = t / CV; v = t - r * CV; }
-    if (v >= CV || r >= R) continue;
+  for (int i = t; i < CVS * 8; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  if (r < R && v < CV) {
+    const uint16_t* xi = x + (long long)n * HW * C + v * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = p_begin + r; p < p_end; p += R) {
-      uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C + v * 8);
+      uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C);
       float f[8];
       unpack8(raw, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += f[e];
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + (long long)n * C + v * 8 + e, s[e] * inv);
+    for (int e = 0; e < 8; ++e) atomicAdd(&lds[vl * 8 + e], s[e]);
+  }
+  __syncthreads();
+  for (int i = t; i < CVS * 8; i += 256) {
+    const int c = blockIdx.z * CVS * 8 + i;
+    if (c < C) atomicAdd(out + (long long)n * C + c, lds[i] * inv);
   }
 }
 
@@ -266,10 +271,15 @@ int ur_avgpool_hw(const void* x, float* out, int N, int HW, int C, ur_stream_t s
   hipStream_t s = (hipStream_t)stream;
   ur::ProfScope prof("avgpool", 0.0, 2.0 * N * (double)HW * C, s);
   ur::zero_async(out, (size_t)N * C * sizeof(float), s);
-  int chunks = (int)std::min<long long>(std::max<long long>(1, (1024 + N - 1) / N), (HW + 31) / 32);
-  int ppb = (HW + chunks - 1) / chunks;
+  const int cv = C / 8;
+  int cvs = cv < 32 ? cv : 32;
+  while (cv % cvs) --cvs;
+  const int slabs = cv / cvs, R = 256 / cvs;
+  long long want = std::max<long long>(1, 2048 / ((long long)N * slabs));
+  int chunks = (int)std::min<long long>(want, std::max(1, HW / (4 * R)));
+  const int ppb = (HW + chunks - 1) / chunks;
   chunks = (HW + ppb - 1) / ppb;
-  hipLaunchKernelGGL(avgpool_kernel, dim3(chunks, N), dim3(256), 0, s, (const uint16_t*)x, out, HW, C, ppb, 1.0f / HW);
+  hipLaunchKernelGGL(avgpool_kernel, dim3(chunks, N, slabs), dim3(256), 0, s, (const uint16_t*)x, out, HW, C, ppb, 1.0f / HW, cvs);
   return ur::check_launch("ur_avgpool_hw");
 }
 

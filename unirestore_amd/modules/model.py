@@ -370,7 +370,7 @@ class DiffUIE(nn.Module):
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):    # an RCCL watchdog thread may be alive
                 outs = self._forward_device(static["images"], task, static["n_vae"], static["n_t"])
             g = self._graphs[key] = (graph, static, outs)
         graph, static, outs = g
