@@ -319,7 +319,10 @@ class DiffUIE(nn.Module):
             ac = schedule.alphas_cumprod_f64()
             zt, ztb = ops.add_noise(z0, n_t, lat, float(np.float32(ac[999] ** 0.5)), float(np.float32((1 - ac[999]) ** 0.5)))
             stem = self.controller.stem(z0b)
+            arena = ops.arena(images.device)
+            mark = arena.mark()
             for i, t in enumerate(self.timesteps):
+                arena.rewind(mark)                       # per-step GroupNorm sums reuse one region (re-zeroed per step)
                 control = self.controller.run(stem, i)
                 eps = self.base_model.run(ztb, control, i)
                 c_x, c_e = schedule.ddim_coefficients(int(t), self.num_inference_steps)

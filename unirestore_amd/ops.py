@@ -58,6 +58,19 @@ class StatsArena:
         if self.high:
             self.buf[:self.high].zero_()
         self.off = 0
+        self._loop_high = 0
+
+    def mark(self):
+        return self.off
+
+    def rewind(self, mark):
+        """Reuse everything allocated since `mark` (one denoise step): re-zero that region and continue from the mark.
+        Statistics produced before the mark (encoder skip features) stay alive."""
+        hi = max(self.off, getattr(self, "_loop_high", 0))
+        self._loop_high = hi
+        if hi > mark:
+            self.buf[mark:hi].zero_()
+        self.off = mark
 
     def alloc(self, n):
         n = round_up(n, 2)
