@@ -220,7 +220,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   }
   const bool pair = is_pair_act(p.act);
   constexpr int SROW = BN * 2 + 8;                       // staged row stride in bytes (+8 spreads the ds_write_b64 banks)
-  const bool staged = p.staged_ok_ && BN >= 32;        // host-evaluated: bf16 y, 16-byte aligned rows, no colsum / per-image bias
+  // per-image bias rows (time embeddings of a schedule-batched Controller): a tile covers 1 image, or up to 4 whole ones
+  const int nimg_tile = (p.bias_img && !p.patch_tw && p.OHW < BM) ? BM / p.OHW : 1;
+  const bool bias_geom_ok = !p.bias_img || p.patch_tw || (p.OHW % BM) == 0 || ((BM % p.OHW) == 0 && nimg_tile <= 4);
+  const bool staged = p.staged_ok_ && BN >= 32 && bias_geom_ok;   // host-evaluated part: bf16 y, 16-byte aligned rows, no colsum
   if (!staged) {
     if (owner) igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
     return;
@@ -228,10 +231,14 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   const int c0 = pair ? (n0 >> 1) : n0;                  // first output column of this tile
   const int ncols = pair ? BN / 2 : BN;
   const int cmax = min(p.yt ? p.n_split : (pair ? p.Cout / 2 : p.Cout), c0 + ncols) - c0;     // valid output columns here
-  float* sbias = reinterpret_cast<float*>(smem + BM * SROW);                                   // BN floats (GEMM-N order)
-  float* facc = sbias + BN;                                                                    // [2][BN] fused GroupNorm sums
-  for (int i = threadIdx.x; i < BN; i += NT)
-    sbias[i] = (p.bias && n0 + i < p.Cout) ? p.bias[gb * p.bs_bias + n0 + i] : 0.f;
+  float* sbias = reinterpret_cast<float*>(smem + BM * SROW);                                   // [nimg_tile][BN] floats (GEMM-N order)
+  float* facc = sbias + 4 * BN;                                                                // [2][BN] fused GroupNorm sums
+  const int img0 = m0 / p.OHW;
+  for (int i = threadIdx.x; i < BN * nimg_tile; i += NT) {
+    const int il = i / BN, col = i - il * BN;
+    const long long boff = gb * p.bs_bias + (p.bias_img ? (long long)min(img0 + il, p.N - 1) * p.bias_img : 0);
+    sbias[i] = (p.bias && n0 + col < p.Cout) ? p.bias[boff + n0 + col] : 0.f;
+  }
   if (p.gn_fused)
     for (int i = threadIdx.x; i < 2 * BN; i += NT) facc[i] = 0.f;
   if (p.res) {                                            // residual tile -> LDS, coalesced
@@ -249,7 +256,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
     for (int rg = 0; rg < 4; ++rg) {
       const int ln = wn * WTN + a * 32 + rg * 8 + fhalf * 4;          // column inside the tile (GEMM-N space)
       const int co_in = n0 + ln;
-      const float4 bv = *reinterpret_cast<const float4*>(sbias + ln);
+      float4 bv = *reinterpret_cast<const float4*>(sbias + ln);
       float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pair) gv = *reinterpret_cast<const float4*>(sbias + ln + 32);
       const int lco = pair ? ((ln >> 6) * 32 + (ln & 31)) : ln;        // column inside the OUTPUT tile
@@ -258,6 +265,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
         const int lm = wm * WTM + b * 32 + mrow;
+        if (nimg_tile > 1) {                                  // tile spans several images: this row's own bias row
+          const int il = lm / p.OHW;
+          bv = *reinterpret_cast<const float4*>(sbias + il * BN + ln);
+          if (pair) gv = *reinterpret_cast<const float4*>(sbias + il * BN + ln + 32);
+        }
         float v[4] = {acc[a][b][rg * 4] + bv.x, acc[a][b][rg * 4 + 1] + bv.y, acc[a][b][rg * 4 + 2] + bv.z,
                       acc[a][b][rg * 4 + 3] + bv.w};
         if (pair) {
@@ -1113,7 +1125,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
 template <int BN, int WM, int WN>
 int launch_halo(ConvK& k, hipStream_t s) {
   constexpr int HBYTES = 48 * 1024;
-  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = 256 * (BN * 2 + 8) + 3 * BN * 4;
+  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = 256 * (BN * 2 + 8) + 6 * BN * 4;
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   k.tiles_m = k.N * (k.OH / 8) * (k.OW / 32);
   k.tiles_n = (k.Cout + BN - 1) / BN;
@@ -1228,7 +1240,7 @@ extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
   k.kcm = d->k_chunk_major;
   UR_REQUIRE(!k.kcm || (k.Cin % 64 == 0 && d->C1 % 64 == 0), "k_chunk_major needs C1 and C1+C2 to be multiples of 64");
   k.gn_stats = d->gn_stats;
-  k.staged_ok_ = d->y && !d->out_f32 && !d->colsum && !d->bias_img_stride && ((d->ldy | d->bs_y) & 7) == 0 &&
+  k.staged_ok_ = d->y && !d->out_f32 && !d->colsum && ((d->ldy | d->bs_y) & 7) == 0 &&
                  (!d->residual || ((d->ldr | d->bs_r) & 7) == 0);
   UR_REQUIRE(!d->gn_stats || (d->y && !d->out_f32 && !d->yt), "gn_stats needs a plain bf16 output");
   hipStream_t s = (hipStream_t)stream;

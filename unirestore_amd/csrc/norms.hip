@@ -20,12 +20,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
   if (r < R && v < CV) {
     const uint16_t* xi = x + (long long)n * HW * C + v * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = p_begin + r; p < p_end; p += R) {
-      uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C);
-      float f[8];
-      unpack8(raw, f);
+    for (int p = p_begin + r; p < p_end; p += 4 * R) {
+      uint4 raw[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+      for (int u = 0; u < 4; ++u) {
+        const int pp = min(p + u * R, p_end - 1);
+        raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)pp * C);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (p + u * R >= p_end) break;
+        float f[8];
+        unpack8(raw[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+      }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -104,16 +113,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
   const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
   const uint16_t* xi = x + (long long)n * HW * C + v * 8;
   uint16_t* yo = y + (long long)n * HW * C_total + c_off + v * 8;
-  for (int p = p_begin + r; p < p_end; p += R) {
-    uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C);
-    float f[8];
-    unpack8(raw, f);
+  for (int p = p_begin + r; p < p_end; p += 4 * R) {        // 4 independent 16-byte loads in flight per thread
+    uint4 raw[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float o = f[e] * a[e] + b[e];
-      f[e] = silu ? silu_f(o) : o;
+    for (int u = 0; u < 4; ++u) {
+      const int pp = min(p + u * R, p_end - 1);
+      raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)pp * C);
     }
-    *reinterpret_cast<uint4*>(yo + (long long)p * C_total) = pack8(f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = p + u * R;
+      if (pp >= p_end) break;
+      float f[8];
+      unpack8(raw[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float o = f[e] * a[e] + b[e];
+        f[e] = silu ? silu_f(o) : o;
+      }
+      *reinterpret_cast<uint4*>(yo + (long long)pp * C_total) = pack8(f);
+    }
   }
 }
 
@@ -161,16 +180,26 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const uint16_t* __r
   const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
   const uint16_t* xi = x + (long long)n * HW * C + v * 8;
   uint16_t* yo = y + (long long)n * HW * C_total + c_off + v * 8;
-  for (int p = p_begin + r; p < p_end; p += R) {
-    uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C);
-    float f[8];
-    unpack8(raw, f);
+  for (int p = p_begin + r; p < p_end; p += 4 * R) {        // 4 independent 16-byte loads in flight per thread
+    uint4 raw[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float o = f[e] * a[e] + b[e];
-      f[e] = silu ? silu_f(o) : o;
+    for (int u = 0; u < 4; ++u) {
+      const int pp = min(p + u * R, p_end - 1);
+      raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)pp * C);
     }
-    *reinterpret_cast<uint4*>(yo + (long long)p * C_total) = pack8(f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = p + u * R;
+      if (pp >= p_end) break;
+      float f[8];
+      unpack8(raw[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float o = f[e] * a[e] + b[e];
+        f[e] = silu ? silu_f(o) : o;
+      }
+      *reinterpret_cast<uint4*>(yo + (long long)pp * C_total) = pack8(f);
+    }
   }
 }
 
@@ -268,7 +297,7 @@ int gn_stats_launch(const void* x, double* stats, int N, int HW, int C, hipStrea
   while (cv % cvs) --cvs;
   const int slabs = cv / cvs, R = 256 / cvs;
   long long want = std::max<long long>(1, 2048 / ((long long)N * slabs));
-  int chunks = (int)std::min<long long>(want, std::max(1, HW / (4 * R)));
+  int chunks = (int)std::min<long long>(want, std::max(1, HW / (8 * R)));
   const int ppb = (HW + chunks - 1) / chunks;
   chunks = (HW + ppb - 1) / ppb;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, N, slabs), dim3(256), 0, s, (const uint16_t*)x, stats, HW, C, ppb, 0, C, cvs);
@@ -306,7 +335,7 @@ int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma
     const int R = 256 / cvs[i];
     // aim for >= ~2048 blocks (8 per CU) but keep >= 4 pixel rows per thread when the tensor is big enough
     long long want = std::max<long long>(1, 2048 / ((long long)N * slabs[i]));
-    chunks[i] = (int)std::min<long long>(want, std::max(1, HW / (4 * R)));
+    chunks[i] = (int)std::min<long long>(want, std::max(1, HW / (8 * R)));
     ppb[i] = (HW + chunks[i] - 1) / chunks[i];
     chunks[i] = (HW + ppb[i] - 1) / ppb[i];
     const double* pre = i == 0 ? pre1 : pre2;

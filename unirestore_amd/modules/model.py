@@ -82,6 +82,19 @@ class Controller(nn.Module):
         feats[-1] = self.middle_block.run(h, step=step)                # replace the last one (controller.py:211)
         return {f.shape[2]: self.fea_tran[i].run(f, step=step) for i, f in enumerate(feats)}   # keyed by WIDTH
 
+    def run_schedule(self, stem, nsteps):
+        """All `nsteps` evaluations of the schedule in ONE batched pass.  control_i = Controller(z0, t_i) never sees zt
+        (unifie.py:148), so the S evaluations are independent: stacking them step-major into a batch of S*B images turns
+        the small 16x16 / 8x8 levels into full MFMA tiles and 20 launches per layer into one.  Per-step time embeddings
+        enter as per-image bias rows.  Returns the list of per-step control dicts (views of the batched outputs)."""
+        b = stem.shape[0]
+        x = stem.repeat(nsteps, 1, 1, 1)
+        g = ops.gn_of(stem)
+        if g is not None:
+            x._gn = g.view(b, -1).repeat(nsteps, 1).view(-1)
+        out = self.run(x, "all")
+        return [{k: v[i * b:(i + 1) * b] for k, v in out.items()} for i in range(nsteps)]
+
     def forward(self, x, timesteps, encoder_hidden_states=None):
         """Reference signature: x (B,4,h,w) fp32 NCHW, timesteps (1,) or (B,) -> {width: (B,256,h',w') fp32}."""
         ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
@@ -263,6 +276,7 @@ class DiffUIE(nn.Module):
         self.tedit = tedit if tedit else None
         self.ae = SkipConnectedAutoEncoder(AutoencoderKL(**(vae_cfg or {})), self.fr_type, self.tedit, fr_depths)
         self.use_graph = use_graph
+        self.batch_controller = os.environ.get("UR_BATCH_CONTROLLER", "1") == "1"
         self._graphs = {}
         if self.control_type:
             ccfg = controller_cfg or stablesr_config
@@ -319,11 +333,12 @@ class DiffUIE(nn.Module):
             ac = schedule.alphas_cumprod_f64()
             zt, ztb = ops.add_noise(z0, n_t, lat, float(np.float32(ac[999] ** 0.5)), float(np.float32((1 - ac[999]) ** 0.5)))
             stem = self.controller.stem(z0b)
+            controls = self.controller.run_schedule(stem, len(self.timesteps)) if self.batch_controller else None
             arena = ops.arena(images.device)
             mark = arena.mark()
             for i, t in enumerate(self.timesteps):
                 arena.rewind(mark)                       # per-step GroupNorm sums reuse one region (re-zeroed per step)
-                control = self.controller.run(stem, i)
+                control = controls[i] if controls is not None else self.controller.run(stem, i)
                 eps = self.base_model.run(ztb, control, i)
                 c_x, c_e = schedule.ddim_coefficients(int(t), self.num_inference_steps)
                 ops.ddim_step_(zt, ztb, eps, lat, c_x, c_e)

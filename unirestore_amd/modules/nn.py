@@ -115,16 +115,31 @@ class ResnetBlock2D(nn.Module):
 
     def set_time_table(self, silu_emb: torch.Tensor):
         """Per-row conv1 bias with the time embedding folded in (rows = schedule steps, or samples)."""
+        for k in [k for k in self.__dict__ if isinstance(k, tuple) and k[:2] == ("cache", "tb_all")]:
+            del self.__dict__[k]
         w, b = self.time_emb_proj.dev_f32()
         cb = self.conv1.bias.detach().float().to(DEV)
         self.tbias = ops.linear_f32(silu_emb, w, b + cb)
 
+    def _tbias_all(self, b):
+        """[S*b, cout] bias rows for a schedule-batched pass (image n = step*b + i uses the row of its step)."""
+        key = ("cache", "tb_all", b)
+        if key not in self.__dict__:
+            self.__dict__[key] = self.tbias.repeat_interleave(b, dim=0).contiguous()
+        return self.__dict__[key]
+
     def run(self, x, x2=None, step=None, sample_bias=None):
-        """x (+x2: virtual concat) NHWC bf16.  step: row of the time table; sample_bias: [N,cout] per-image rows."""
+        """x (+x2: virtual concat) NHWC bf16.  step: row of the time table, or "all" when the batch stacks every step of
+        the schedule (step-major); sample_bias: explicit [N,cout] per-image rows."""
         h = self.norm1.run(x, silu=True, x2=x2)
         bias = None
         if self.time_emb_proj is not None:
-            bias = sample_bias if sample_bias is not None else self.tbias[step]
+            if sample_bias is not None:
+                bias = sample_bias
+            elif isinstance(step, str):
+                bias = self._tbias_all(x.shape[0] // self.tbias.shape[0])
+            else:
+                bias = self.tbias[step]
         h = ops.conv(h, self.conv1.packed(), bias=bias, gn=True)
         h = self.norm2.run(h, silu=True)
         if self.conv_shortcut is not None:
