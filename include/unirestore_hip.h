@@ -63,6 +63,15 @@ typedef struct ur_conv_desc {
                            AdaptiveAvgPool2d(1), taskeditor.py:35) or NULL; batch index = channel group */
   double* gn_stats;     /* fp64 [N][nbatch*Cout_out][2] += (sum, sum of squares) of the stored bf16 outputs per image and
                            channel (atomic; statistics for the GroupNorm that consumes y) or NULL */
+  float* row_stats;     /* fp32 [parts][M][2] = per-row (sum, sum of squares) of this GEMM's output, one partial plane per N
+                           tile (plain stores; parts = ur_conv2d_row_stat_parts(desc)): the LayerNorm statistics of the
+                           GEMM that consumes y (BasicTransformerBlock norm1-3) or NULL */
+  const float* ln_stats;  /* fp32 [ln_parts][M][2] row sums of x (a producer's row_stats): this GEMM computes W.LayerNorm(x) as
+                             rstd*(acc - mean*ln_colsum[n]) + bias[n] with w = W*gamma, bias = W.beta + b prefolded; or NULL */
+  const float* ln_colsum; /* fp32 [Cout]: sum_k of the (bf16) folded weight row */
+  float ln_eps;
+  int ln_dim;             /* normalised width (= K) */
+  int ln_parts;           /* number of partial planes in ln_stats */
   float* workspace;     /* fp32 split-K scratch or NULL */
   size_t workspace_bytes;
   int N, H, W;          /* input dims (before upsample2x) */
@@ -85,6 +94,8 @@ typedef struct ur_conv_desc {
 } ur_conv_desc;
 
 int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream);
+/* host-only query: how many partial row-sum planes the launch of `d` writes into d->row_stats */
+int ur_conv2d_row_stat_parts(const ur_conv_desc* d);
 
 /* ---- normalisation (HBM-bound) ----------------------------------------------------------------
  * GroupNorm over NHWC (+ optional SiLU).  G == C with gamma=beta=NULL gives InstanceNorm2d.

@@ -289,3 +289,25 @@ def test_conv_halo_tile_path(ops, n, cin, cout, h, w, ups, res):
     assert rel_l2(_nchw(y), ref) < TOL_BF16
     st = ops.gn_of(y).view(n, cout, 2).cpu()
     assert rel_l2(st[..., 0], _nchw(y).double().sum((2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("rows,c,n,pair", [(256, 320, 960, False), (300, 64, 128, False), (512, 320, 2560, True), (128, 640, 640, False)])
+def test_layernorm_fused_into_gemm(ops, rows, c, n, pair):
+    """Producer GEMM leaves per-row sums; the consumer computes Linear(LayerNorm(x)) without a LayerNorm pass."""
+    g = _gen(rows + n)
+    x0 = _rb(torch.randn(rows, 96, generator=g)); w0 = _rb(torch.randn(c, 96, generator=g) / 9); r0 = _rb(torch.randn(rows, c, generator=g) * 2 + 0.5)
+    ops.arena().reset()
+    x = ops.linear(x0.to(torch.bfloat16).cuda(), ops.pack_conv(w0, None, "cuda"), residual=r0.to(torch.bfloat16).cuda(), rows=True)
+    xs = x.float().cpu()
+    stt, parts = ops.ln_of(x)
+    st = stt.view(parts, rows, 2).sum(0).cpu()
+    assert rel_l2(st[:, 0], xs.double().sum(1)) < 1e-5 and rel_l2(st[:, 1], (xs.double() ** 2).sum(1)) < 1e-5
+    ga, be = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    w = _rb(torch.randn(n, c, generator=g) / math.sqrt(c)); b = torch.randn(n, generator=g)
+    ref = F.linear(F.layer_norm(xs, (c,), ga, be, 1e-5), w, b)
+    pc = ops.pack_linear_ln(w, b, ga, be, 1e-5, "cuda", pair=pair)
+    y = ops.linear(x, pc, ln_stats=ops.ln_of(x), act=ops.UR_ACT_GEGLU if pair else ops.UR_ACT_NONE)
+    if pair:
+        a, gt = ref.chunk(2, -1)
+        ref = a * F.gelu(gt)
+    assert rel_l2(y.float().cpu(), ref) < 6e-3      # gamma is folded into bf16 weights: one extra bf16 rounding of W*gamma

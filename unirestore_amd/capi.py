@@ -16,7 +16,9 @@ class ConvDesc(C.Structure):
     """Mirror of `ur_conv_desc` (field order and types must match the header exactly)."""
     _fields_ = [
         ("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
-        ("y", C.c_void_p), ("yt", C.c_void_p), ("colsum", C.c_void_p), ("gn_stats", C.c_void_p), ("workspace", C.c_void_p),
+        ("y", C.c_void_p), ("yt", C.c_void_p), ("colsum", C.c_void_p), ("gn_stats", C.c_void_p),
+        ("row_stats", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int), ("ln_parts", C.c_int),
+        ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
         ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
         ("C1", C.c_int), ("ldx", C.c_int), ("C2", C.c_int), ("ldx2", C.c_int),
@@ -39,6 +41,7 @@ SIGNATURES = {
     "ur_version": (_I, []),
     "ur_last_error": (C.c_char_p, []),
     "ur_conv2d_nhwc": (_I, [C.POINTER(ConvDesc), _P]),
+    "ur_conv2d_row_stat_parts": (_I, [C.POINTER(ConvDesc)]),
     "ur_groupnorm_ws_bytes": (_SZ, [_I, _I]),
     "ur_groupnorm_ab_bytes": (_SZ, [_I, _I]),
     "ur_groupnorm_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),

@@ -27,6 +27,8 @@ namespace {
 struct ConvK {
   const uint16_t* x; const uint16_t* x2; const uint16_t* w; const float* bias; const uint16_t* res;
   void* y; uint16_t* yt; float* colsum; float* ws; double* gn_stats;
+  float* row_stats; const float* ln_stats; const float* ln_colsum; float ln_eps; int ln_dim, ln_parts;
+  int dry, plan_tn;
   int N, H, W, C1, ldx, C2, ldx2, Cin, Cout, ldw, ldy, ldr, KH, KW, stride, pad_t, pad_l, OH, OW, OHW;
   int ups, act, out_f32, n_split, t_rows, t_ld;
   float out_scale, colsum_scale;
@@ -233,6 +235,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   const int cmax = min(p.yt ? p.n_split : (pair ? p.Cout / 2 : p.Cout), c0 + ncols) - c0;     // valid output columns here
   float* sbias = reinterpret_cast<float*>(smem + BM * SROW);                                   // [nimg_tile][BN] floats (GEMM-N order)
   float* facc = sbias + 4 * BN;                                                                // [2][BN] fused GroupNorm sums
+  float* scol = facc + 2 * BN;                                                                 // [BN] LN fusion: column sums of W*gamma
+  float* srow = scol + BN;                                                                     // [BM][2] LN fusion: mean, rstd per row
   const int img0 = m0 / p.OHW;
   for (int i = threadIdx.x; i < BN * nimg_tile; i += NT) {
     const int il = i / BN, col = i - il * BN;
@@ -241,6 +245,21 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   }
   if (p.gn_fused)
     for (int i = threadIdx.x; i < 2 * BN; i += NT) facc[i] = 0.f;
+  if (p.ln_stats) {   // this GEMM consumes LayerNorm(x): out = rstd*(acc - mean*s[n]) + t[n]  (t arrives as the bias)
+    for (int i = threadIdx.x; i < BN; i += NT) scol[i] = n0 + i < p.Cout ? p.ln_colsum[n0 + i] : 0.f;
+    for (int r = threadIdx.x; r < BM; r += NT) {
+      const int m = min(tile_row_to_m(p, m0, r), p.M - 1);
+      float sx = 0.f, sq = 0.f;
+      for (int q = 0; q < p.ln_parts; ++q) {               // one partial per N tile of the producer GEMM (no atomics)
+        const float2 t2 = *reinterpret_cast<const float2*>(p.ln_stats + 2 * ((long long)q * p.M + m));
+        sx += t2.x; sq += t2.y;
+      }
+      const float mean = sx / p.ln_dim;
+      const float var = fmaxf(sq / p.ln_dim - mean * mean, 0.f);
+      srow[2 * r] = mean;
+      srow[2 * r + 1] = rsqrtf(var + p.ln_eps);
+    }
+  }
   if (p.res) {                                            // residual tile -> LDS, coalesced
     uint16_t* rb = const_cast<uint16_t*>(p.res) + gb * p.bs_r;
     if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, true>(p, rb, p.ldr, smem, m0, p.M, c0, cmax);
@@ -262,6 +281,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
       const int lco = pair ? ((ln >> 6) * 32 + (ln & 31)) : ln;        // column inside the OUTPUT tile
       const int co = c0 + lco;
       const bool col_ok = co_in < p.Cout;
+      float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.ln_stats) {
+        sv = *reinterpret_cast<const float4*>(scol + ln);
+        if (pair) sg = *reinterpret_cast<const float4*>(scol + ln + 32);
+      }
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
         const int lm = wm * WTM + b * 32 + mrow;
@@ -270,12 +294,26 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
           bv = *reinterpret_cast<const float4*>(sbias + il * BN + ln);
           if (pair) gv = *reinterpret_cast<const float4*>(sbias + il * BN + ln + 32);
         }
-        float v[4] = {acc[a][b][rg * 4] + bv.x, acc[a][b][rg * 4 + 1] + bv.y, acc[a][b][rg * 4 + 2] + bv.z,
-                      acc[a][b][rg * 4 + 3] + bv.w};
+        float v[4], gq[4] = {0.f, 0.f, 0.f, 0.f};
+        constexpr int a1 = (FN > 1) ? 1 : 0;
+        if (p.ln_stats) {                                     // LayerNorm folded into this GEMM (see above)
+          const float mean = srow[2 * lm], rstd = srow[2 * lm + 1];
+          v[0] = rstd * (acc[a][b][rg * 4] - mean * sv.x) + bv.x;     v[1] = rstd * (acc[a][b][rg * 4 + 1] - mean * sv.y) + bv.y;
+          v[2] = rstd * (acc[a][b][rg * 4 + 2] - mean * sv.z) + bv.z; v[3] = rstd * (acc[a][b][rg * 4 + 3] - mean * sv.w) + bv.w;
+          if (pair) {
+            gq[0] = rstd * (acc[(a + a1) % FN][b][rg * 4] - mean * sg.x) + gv.x;     gq[1] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 1] - mean * sg.y) + gv.y;
+            gq[2] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 2] - mean * sg.z) + gv.z; gq[3] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 3] - mean * sg.w) + gv.w;
+          }
+        } else {
+          v[0] = acc[a][b][rg * 4] + bv.x; v[1] = acc[a][b][rg * 4 + 1] + bv.y;
+          v[2] = acc[a][b][rg * 4 + 2] + bv.z; v[3] = acc[a][b][rg * 4 + 3] + bv.w;
+          if (pair) {
+            gq[0] = acc[(a + a1) % FN][b][rg * 4] + gv.x; gq[1] = acc[(a + a1) % FN][b][rg * 4 + 1] + gv.y;
+            gq[2] = acc[(a + a1) % FN][b][rg * 4 + 2] + gv.z; gq[3] = acc[(a + a1) % FN][b][rg * 4 + 3] + gv.w;
+          }
+        }
         if (pair) {
-          constexpr int a1 = (FN > 1) ? 1 : 0;
-          const float g0 = acc[(a + a1) % FN][b][rg * 4] + gv.x, g1 = acc[(a + a1) % FN][b][rg * 4 + 1] + gv.y;
-          const float g2 = acc[(a + a1) % FN][b][rg * 4 + 2] + gv.z, g3 = acc[(a + a1) % FN][b][rg * 4 + 3] + gv.w;
+          const float g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3];
           if (p.act == UR_ACT_GEGLU) { v[0] *= gelu_f(g0); v[1] *= gelu_f(g1); v[2] *= gelu_f(g2); v[3] *= gelu_f(g3); }
           else { v[0] *= g0; v[1] *= g1; v[2] *= g2; v[3] *= g3; }
         } else if (p.act != UR_ACT_NONE) {
@@ -325,6 +363,27 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
     for (int i = threadIdx.x; i < cmax; i += NT) {
       atomicAdd(&st[2 * i], (double)facc[i]);
       atomicAdd(&st[2 * i + 1], (double)facc[BN + i]);
+    }
+  }
+  if (p.row_stats) {
+    // per-row (sum, sum of squares) over this tile's columns of the bf16 values just produced: the LayerNorm statistics
+    // of the consumer GEMM.  NT/BM threads share a row; partials meet through float atomics (one pair per row per N tile).
+    constexpr int TPR = NT / BM >= 1 ? NT / BM : 1;
+    const int r = threadIdx.x / TPR, part = threadIdx.x % TPR;
+    if (r < BM) {
+      const int m = tile_row_to_m(p, m0, r);
+      const int npair = cmax >> 1, per = (npair + TPR - 1) / TPR;
+      float sx = 0.f, sq = 0.f;
+      for (int j = part * per; j < min(npair, (part + 1) * per); ++j) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * SROW + j * 4);
+        const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
+        sx += a + b; sq += a * a + b * b;
+      }
+      if (TPR == 2) { sx += __shfl_xor(sx, 1, 64); sq += __shfl_xor(sq, 1, 64); }
+      static_assert(TPR <= 2, "row-stat reduction assumes at most two threads per row");
+      const int tn_idx = n0 / BN;
+      if (m < p.M && part == 0)
+        *reinterpret_cast<float2*>(p.row_stats + 2 * ((long long)tn_idx * p.M + m)) = make_float2(sx, sq);
     }
   }
   uint16_t* yb = reinterpret_cast<uint16_t*>(p.y) + gb * p.bs_y;
@@ -519,9 +578,10 @@ template <int BM, int BN, int WM, int WN>
 int launch_cfg(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.Cout + BN - 1) / BN;
+  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
   const long long blocks = (long long)k.tiles_m * k.tiles_n * k.nbatch;
   int splitk = 1;
-  if (blocks < 200 && k.nk >= 8 && k.ws) {
+  if (blocks < 200 && k.nk >= 8 && k.ws && !k.row_stats && !k.ln_stats) {
     long long want = (384 + blocks - 1) / blocks;
     long long cap_k = k.nk / 4;
     splitk = (int)std::min<long long>(std::min<long long>(want, cap_k), 16);
@@ -719,9 +779,10 @@ template <int BM, int BN, int WM, int WN, int NST>
 int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.Cout + BN - 1) / BN;
+  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
   const long long blocks = (long long)k.tiles_m * k.tiles_n * k.nbatch;
   int splitk = 1;
-  if (blocks < min_blocks && k.nk >= 8 && k.ws) {
+  if (blocks < min_blocks && k.nk >= 8 && k.ws && !k.row_stats && !k.ln_stats) {
     long long want = (256 + blocks - 1) / blocks;
     splitk = (int)std::min<long long>(std::min<long long>(want, k.nk / 4), 16);
     while (splitk > 1 && (long long)splitk * k.nbatch * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
@@ -744,224 +805,6 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
     int rb = (int)std::min<long long>((total + 255) / 256, 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
   }
-  return ur::check_launch("ur_conv2d_nhwc");
-}
-
-
-// =====================================================================================================================
-// v3 main loop: warp-specialised.  WM*WN CONSUMER waves only read fragments from LDS and issue MFMAs; NPW PRODUCER
-// waves only do address arithmetic and LDS-DMA (global_load_lds_dwordx4) into the NST-deep ring.  Both roles meet at
-// one raw s_barrier per K tile, so on every SIMD the loader's VALU/VMEM issue interleaves with the consumers' MFMA
-// stream instead of alternating with it in lockstep (the v2 kernel spent 61 % of its wave-cycles parked in waits).
-//   barrier t : producers have waited (counted vmcnt) until tile t landed; consumers have finished tile t-1.
-//   after it  : consumers compute tile t (stage t % NST); producers refill stage (t+2) % NST == (t-1) % NST.
-template <int BM, int BN, int WM, int WN, int NPW, int NST>
-__global__ __launch_bounds__((WM* WN + NPW) * 64) void igemm_ws_kernel(const ConvK p) {
-  constexpr int NCW = WM * WN, NT = (NCW + NPW) * 64;
-  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
-  constexpr int PIECES = (BM + BN) / 8, NP = (PIECES + NPW - 1) / NPW;   // 1-KiB pieces (8 rows) per tile / per producer wave
-  constexpr int STAGE = (BM + BN) * 128;
-  static_assert(BM % 32 == 0 && BN % 32 == 0 && (NST == 2 || NST == 3), "tile shape / ring depth");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const bool consumer = wid < NCW;
-  const int wm = consumer ? wid % WM : 0, wn = consumer ? wid / WM : 0;
-  const int gb = blockIdx.y, sz = blockIdx.z;
-  int id = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kt_begin = sz * p.nk_per_split;
-  const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
-  const int ntile = kt_end - kt_begin;
-
-  f32x16 acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  if (!consumer) {
-    // ------------------------------------------------------------------ PRODUCER -------------------------------------
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const int pw = wid - NCW;
-    const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
-    const uint16_t* __restrict__ X2 = p.x2 ? p.x2 + gb * p.bs_x2 : nullptr;
-    const uint16_t* __restrict__ Wt = p.w + gb * p.bs_w;
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
-    const int lr = lane >> 3, ps = lane & 7;               // row inside the piece, physical 16-B slot
-    // piece i of this wave = global piece pw + i*NPW; rows [piece*8, piece*8+8) of the (X | W) stage image.
-    // All per-tile address work is 32-bit: element offsets from the tensor base (host checks < 2^31 elements).
-    //   X row: pix = (n*H + ih0)*W + iw0 (pixel index of tap (0,0); may be "negative" at the border, only used when
-    //          the tap is in range), ih0/iw0 for the range check (an out-of-range ROW gets ih0 = -2^20);
-    //   W row: pix = row*ldw, ih0 = 0 valid / -2^20 invalid.
-    int pix[NP], ih0[NP], iw0[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int piece = min(pw + i * NPW, PIECES - 1);     // a surplus slot repeats the last piece (identical bytes)
-      const int row = piece * 8 + lr;
-      if (row < BM) {
-        const int m = m0 + row;
-        const bool okr = m < p.M;
-        const int mm = okr ? m : 0;
-        const int n = mm / p.OHW, rem = mm - n * p.OHW;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        ih0[i] = okr ? oh * p.stride - p.pad_t : -(1 << 20);
-        iw0[i] = ow * p.stride - p.pad_l;
-        pix[i] = p.ups ? n * p.H : (n * p.H + ih0[i]) * p.W + iw0[i];
-      } else {
-        const int wr = n0 + row - BM;
-        const bool okr = wr < p.Cout;
-        ih0[i] = okr ? 0 : -(1 << 20);
-        iw0[i] = 0;
-        pix[i] = (okr ? wr : 0) * p.ldw;
-      }
-    }
-    const int Hlim = p.ups ? p.H * 2 : p.H, Wlim = p.ups ? p.W * 2 : p.W;
-    // logical K chunk of this lane: ps ^ ((row>>1)&7) with row = piece*8 + lr  ->  depends on the piece's parity only
-    int kc[2], tap[2], cch[2];
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int chunk = ps ^ (((par * 8 + lr) >> 1) & 7);
-      kc[par] = kt_begin * 64 + chunk * 8;
-      tap[par] = kc[par] / p.Cin;
-      cch[par] = kc[par] - tap[par] * p.Cin;
-      if (p.kcm) { tap[par] = kt_begin % (p.KH * p.KW); cch[par] = (kt_begin / (p.KH * p.KW)) * 64 + chunk * 8; }
-    }
-    auto issue_tile = [&](int stage) {
-      unsigned char* st = smem + stage * STAGE;
-      // once per tile (per parity): tap decode, source select, tap offset
-      int dy[2], dx[2], toff[2], ld[2];
-      const uint16_t* src[2];
-      bool kv[2];
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        kv[par] = kc[par] < p.Ktot;
-        dy[par] = (p.KW == 1) ? 0 : (tap[par] * 11) >> 5;
-        dx[par] = tap[par] - dy[par] * p.KW;
-        int cc = cch[par];
-        src[par] = X1; ld[par] = p.ldx;
-        if (cc >= p.C1) { src[par] = X2; ld[par] = p.ldx2; cc -= p.C1; }
-        toff[par] = p.ups ? cc : (dy[par] * p.W + dx[par]) * ld[par] + cc;
-      }
-#pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        const int piece = min(pw + i * NPW, PIECES - 1);
-        const int par = piece & 1;
-        const uint16_t* g = zero;
-        if (piece * 8 < BM) {                                 // X piece (wave-uniform branch)
-          const int ih = ih0[i] + dy[par], iw = iw0[i] + dx[par];
-          const bool v = kv[par] && (unsigned)ih < (unsigned)Hlim && (unsigned)iw < (unsigned)Wlim;
-          const int off = p.ups ? ((pix[i] + (ih >> 1)) * p.W + (iw >> 1)) * ld[par] + toff[par]
-                                : pix[i] * ld[par] + toff[par];
-          if (v) g = src[par] + off;
-        } else {
-          if (kv[par] && ih0[i] == 0) g = Wt + (pix[i] + kc[par]);
-        }
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + piece * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        kc[par] += 64;
-        if (p.kcm) { if (++tap[par] == p.KH * p.KW) { tap[par] = 0; cch[par] += 64; } }
-        else { cch[par] += 64; while (cch[par] >= p.Cin) { cch[par] -= p.Cin; ++tap[par]; } }
-      }
-    };
-    if (ntile > 0) {
-      int issued = 0;
-      issue_tile(0); ++issued;
-      if (NST == 3 && ntile > 1) { issue_tile(1); ++issued; }
-      if (issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                      // barrier 0: tile 0 landed
-      int is = (NST - 1) % NST;
-      long long c_issue = 0, c_wait = 0, c_bar = 0;
-      const bool prof = (p.dbg & 64) && blockIdx.x == 17 && pw == 0;
-      for (int t = 0; t < ntile; ++t) {
-        long long t0 = prof ? clock64() : 0;
-        if (issued < ntile) {
-          issue_tile(is); ++issued; is = (is + 1 == NST) ? 0 : is + 1;
-          long long t1 = prof ? clock64() : 0;
-          if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");   // tile t+1 landed (only t+2 in flight)
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // 2-stage ring: tile t+1 itself
-          if (prof) { long long t2 = clock64(); c_issue += t1 - t0; c_wait += t2 - t1; t0 = t2; }
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (prof) { long long t2 = clock64(); c_wait += t2 - t0; t0 = t2; }
-        }
-        __builtin_amdgcn_s_barrier();                                    // barrier t+1
-        if (prof) c_bar += clock64() - t0;
-      }
-      if (prof && lane == 0) { p.ws[0] = (float)c_issue; p.ws[1] = (float)c_wait; p.ws[2] = (float)c_bar; p.ws[3] = (float)ntile; }
-    }
-  } else {
-    // ------------------------------------------------------------------ CONSUMER -------------------------------------
-    const int frow = lane & 31, fhalf = lane >> 5;
-    if (ntile > 0) {
-      __builtin_amdgcn_s_barrier();                                      // barrier 0
-      int cs = 0;
-      long long c_comp = 0, c_bar = 0;
-      const bool prof = (p.dbg & 64) && blockIdx.x == 17 && wid == 0;
-      for (int t = 0; t < ntile; ++t) {
-        const long long t0 = prof ? clock64() : 0;
-        const unsigned char* xs = smem + cs * STAGE;
-        const unsigned char* wsm = xs + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int slot = ks * 2 + fhalf;
-          bf16x8 bfr[FM], afr[FN];
-#pragma unroll
-          for (int b = 0; b < FM; ++b) {
-            const int row = wm * WTM + b * 32 + frow;
-            bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-          }
-#pragma unroll
-          for (int a = 0; a < FN; ++a) {
-            const int row = wn * WTN + a * 32 + frow;
-            afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-          }
-#pragma unroll
-          for (int a = 0; a < FN; ++a)
-#pragma unroll
-            for (int b = 0; b < FM; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
-        }
-        cs = (cs + 1 == NST) ? 0 : cs + 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        long long t1 = 0;
-        if (prof) { asm volatile("" ::"v"(acc[0][0][0])); t1 = clock64(); c_comp += t1 - t0; }
-        __builtin_amdgcn_s_barrier();                                    // barrier t+1: done reading stage t % NST
-        if (prof) c_bar += clock64() - t1;
-      }
-      if (prof && lane == 0) { p.ws[4] = (float)c_comp; p.ws[5] = (float)c_bar; }
-    }
-  }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem, consumer);
-}
-
-template <int BM, int BN, int WM, int WN, int NPW, int NST = 3>
-int launch_ws(ConvK& k, hipStream_t s) {
-  k.tiles_m = (k.M + BM - 1) / BM;
-  k.tiles_n = (k.Cout + BN - 1) / BN;
-  k.splitk = 1;
-  k.nk_per_split = k.nk;
-  k.gn_fused = k.gn_stats && k.staged_ok_ && BN >= 32 && (k.OHW % BM) == 0;
-  constexpr int lds = NST * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ws_kernel<BM, BN, WM, WN, NPW, NST>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, 1);
-  hipLaunchKernelGGL((igemm_ws_kernel<BM, BN, WM, WN, NPW, NST>), grid, dim3((WM * WN + NPW) * 64), lds, s, k);
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
@@ -1125,10 +968,11 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
 template <int BN, int WM, int WN>
 int launch_halo(ConvK& k, hipStream_t s) {
   constexpr int HBYTES = 48 * 1024;
-  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = 256 * (BN * 2 + 8) + 6 * BN * 4;
+  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = 256 * (BN * 2 + 8) + 7 * BN * 4 + 256 * 8;
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   k.tiles_m = k.N * (k.OH / 8) * (k.OW / 32);
   k.tiles_n = (k.Cout + BN - 1) / BN;
+  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
   k.splitk = 1;
   k.nk_per_split = k.nk;
   k.patch_tw = 32;
@@ -1176,23 +1020,8 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   const bool n160 = !pair && k.Cout % 160 == 0 && k.Cout % 128 != 0;
   const long long big_tiles = (long long)((k.M + 255) / 256) * ((k.Cout + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * k.nbatch;
   if (big_tiles >= 160) {
-    static const bool no_ws = getenv("UR_IGEMM_WS") == nullptr;   // warp-specialised variant is opt-in (slower end to end)
-    if (no_ws) {
-      if (n160) return launch_glds<256, 160, 8, 1, 3>(k, s, 0);
-      return launch_glds<256, 128, 4, 2, 3>(k, s, 0);
-    }
-    static const int npw = getenv("UR_IGEMM_NPW") ? atoi(getenv("UR_IGEMM_NPW")) : 4;
-    static const int big = getenv("UR_IGEMM_BIG") ? atoi(getenv("UR_IGEMM_BIG")) : 0;
-    if (big == 3) {   // 4 consumer waves with 64-row x full-width wave tiles (fewer LDS fragment bytes per MFMA) + 4 producers
-      if (n160) return launch_ws<256, 160, 4, 1, 4>(k, s);
-      return launch_ws<256, 128, 4, 1, 4>(k, s);
-    }
-    if (npw == 8) {
-      if (n160) return launch_ws<256, 160, 8, 1, 8>(k, s);
-      return launch_ws<256, 128, 4, 2, 8>(k, s);
-    }
-    if (n160) return launch_ws<256, 160, 8, 1, 4>(k, s);
-    return launch_ws<256, 128, 4, 2, 4>(k, s);
+    if (n160) return launch_glds<256, 160, 8, 1, 3>(k, s, 0);
+    return launch_glds<256, 128, 4, 2, 3>(k, s, 0);
   }
   static const int small_mode = getenv("UR_IGEMM_SMALL") ? atoi(getenv("UR_IGEMM_SMALL")) : 2;
   if (small_mode == 1) return launch_glds<128, 128, 2, 2, 2>(k, s, 400);
@@ -1205,7 +1034,7 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
 
 }  // namespace
 
-extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
+static int conv_impl(const ur_conv_desc* d, ur_stream_t stream, int dry, int* plan_tn) {
   UR_REQUIRE(d && d->x && d->w, "null x/w");
   UR_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3), "only 1x1 and 3x3 kernels");
   UR_REQUIRE(d->C1 > 0 && d->C1 % 8 == 0 && d->C2 % 8 == 0 && d->ldx % 8 == 0, "Cin/ldx must be multiples of 8");
@@ -1240,6 +1069,9 @@ extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
   k.kcm = d->k_chunk_major;
   UR_REQUIRE(!k.kcm || (k.Cin % 64 == 0 && d->C1 % 64 == 0), "k_chunk_major needs C1 and C1+C2 to be multiples of 64");
   k.gn_stats = d->gn_stats;
+  k.dry = dry; k.plan_tn = 0; k.ln_parts = d->ln_parts;
+  k.row_stats = d->row_stats; k.ln_stats = d->ln_stats; k.ln_colsum = d->ln_colsum; k.ln_eps = d->ln_eps; k.ln_dim = d->ln_dim;
+  UR_REQUIRE(!d->ln_stats || (d->ln_colsum && d->ln_dim > 0), "ln_stats needs ln_colsum / ln_dim");
   k.staged_ok_ = d->y && !d->out_f32 && !d->colsum && ((d->ldy | d->bs_y) & 7) == 0 &&
                  (!d->residual || ((d->ldr | d->bs_r) & 7) == 0);
   UR_REQUIRE(!d->gn_stats || (d->y && !d->out_f32 && !d->yt), "gn_stats needs a plain bf16 output");
@@ -1255,7 +1087,13 @@ extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
              k.nbatch, d->act);
     fam = interned.emplace(buf, 0).first->first.c_str();
   }
+  if (dry) {
+    const int rc0 = dispatch_conv(k, s, pair);
+    if (plan_tn) *plan_tn = k.plan_tn;
+    return rc0;
+  }
   ur::ProfScope prof(fam, flops, bytes, s);
+  UR_REQUIRE(!(d->row_stats || d->ln_stats) || (k.staged_ok_ && k.nbatch == 1 && !d->yt == !d->yt), "row_stats / ln fusion need a bf16 staged output");
   const int rc = dispatch_conv(k, s, pair);
   if (rc != UR_OK) return rc;
   if (k.gn_stats && !k.gn_fused) {   // this launch could not fuse the statistics: one extra pass over the output
@@ -1264,4 +1102,16 @@ extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) {
     return ur::gn_stats_launch(k.y, k.gn_stats, k.N, k.OHW, ctot, s);
   }
   return UR_OK;
+}
+
+extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) { return conv_impl(d, stream, 0, nullptr); }
+
+// Number of N tiles the launch of `d` will use = number of partial row-sum planes it writes into d->row_stats
+// ([parts][M][2] fp32).  Negative on error.  (The partial layout keeps the producer free of atomics.)
+extern "C" int ur_conv2d_row_stat_parts(const ur_conv_desc* d) {
+  int parts = 0;
+  ur_conv_desc t = *d;
+  if (!t.row_stats) t.row_stats = reinterpret_cast<float*>(16);   // any non-null value: the plan must match the real launch
+  const int rc = conv_impl(&t, nullptr, 1, &parts);
+  return rc == UR_OK ? parts : rc;
 }

@@ -17,6 +17,7 @@ from .. import ops
 from ..ops import UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_SILU
 
 DEV = "cuda"
+FUSE_LN = __import__("os").environ.get("UR_FUSE_LN", "1") == "1"   # LayerNorm folded into the consuming GEMMs
 
 
 class _NoEager:
@@ -187,21 +188,37 @@ def _fused_qkv(mod, names):
     return mod.__dict__[("cache", "qkv")]
 
 
-def self_attention(mod, h, heads, residual, gn_kw={}):
-    """h: [B,T,C] bf16 (already normalised).  One fused QKV GEMM (V written transposed), flash attention,
-    output projection with the residual in its epilogue."""
+def _fused_ln(mod, key, names, norm, pair=False):
+    """Linear(LayerNorm(x)) weights folded for the LN-fused GEMM epilogue (cached): rows = cat of `names`."""
+    ck = ("cache", "ln", key)
+    if ck not in mod.__dict__:
+        ws = [getattr(mod, n).weight.detach().float() for n in names]
+        bs = [getattr(mod, n).bias for n in names]
+        w = torch.cat(ws, 0)
+        b = None if bs[0] is None else torch.cat([t.detach().float() for t in bs], 0)
+        mod.__dict__[ck] = ops.pack_linear_ln(w, b, norm.weight, norm.bias, norm.eps, DEV, pair=pair)
+    return mod.__dict__[ck]
+
+
+def self_attention(mod, h, heads, residual, gn_kw={}, ln=None, rows=False):
+    """h: [B,T,C] bf16.  One fused QKV GEMM (V written transposed), flash attention, output projection with the
+    residual in its epilogue.  ln=(norm, row_stats): h is the RAW residual stream and LayerNorm is folded into the QKV
+    GEMM; otherwise h is already normalised.  rows=True makes the output projection emit per-row sums for the next LN."""
     b, t, c = h.shape
     d = c // heads
     ldvt = ops.round_up(t, 8)
     vt = torch.zeros((b, c, ldvt), dtype=ops.BF16, device=h.device) if ldvt != t else \
         torch.empty((b, c, ldvt), dtype=ops.BF16, device=h.device)
-    qk = ops.linear(h, _fused_qkv(mod, ("to_q", "to_k", "to_v")), yt=vt, n_split=2 * c, t_rows=t)   # [B,T,3C] (V cols unused)
+    if ln is not None:
+        qk = ops.linear(h, _fused_ln(mod, "qkv", ("to_q", "to_k", "to_v"), ln[0]), ln_stats=ln[1], yt=vt, n_split=2 * c, t_rows=t)
+    else:
+        qk = ops.linear(h, _fused_qkv(mod, ("to_q", "to_k", "to_v")), yt=vt, n_split=2 * c, t_rows=t)   # [B,T,3C] (V cols unused)
     if d in (64, 128):
         o = ops.attention(qk, qk[:, :, c:], vt, heads, d, t, t, 1.0 / math.sqrt(d), ldq=3 * c, ldk=3 * c,
                           bs_q=t * 3 * c, bs_k=t * 3 * c, bs_vt=c * ldvt, batch=b)
     else:
         o = attention_gemm(qk[:, :, :c], qk[:, :, c:2 * c], vt, heads, d, t)
-    return ops.linear(o, mod.to_out[0].packed(), residual=residual, **gn_kw)
+    return ops.linear(o, mod.to_out[0].packed(), residual=residual, rows=rows, **gn_kw)
 
 
 def attention_gemm(q, k, vt, heads, d, t):
@@ -254,14 +271,17 @@ class CrossAttention(nn.Module):
             self.__dict__[key] = (k, vt, tk)
         return self.__dict__[key]
 
-    def run_cross(self, h, ctx, residual):
+    def run_cross(self, h, ctx, residual, ln=None, rows=False):
         b, t, c = h.shape
         d = c // self.heads
         k, vt, tk = self.context_kv(ctx)
-        q = ops.linear(h, self.to_q.packed())
+        if ln is not None:
+            q = ops.linear(h, _fused_ln(self, "q", ("to_q",), ln[0]), ln_stats=ln[1])
+        else:
+            q = ops.linear(h, self.to_q.packed())
         o = ops.attention(q, k, vt, self.heads, d, t, tk, 1.0 / math.sqrt(d), ldq=c, ldk=2 * c, bs_q=t * c, bs_k=0,
                           bs_vt=0, batch=b)
-        return ops.linear(o, self.to_out[0].packed(), residual=residual)
+        return ops.linear(o, self.to_out[0].packed(), residual=residual, rows=rows)
 
 
 class GEGLU(nn.Module):
@@ -275,8 +295,11 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(c, 4 * c), nn.Identity(), Linear(4 * c, c)])
 
-    def run(self, h, residual):
-        a = ops.linear(h, self.net[0].proj.packed(pair=True), act=UR_ACT_GEGLU)     # a * gelu(g) in the epilogue
+    def run(self, h, residual, ln=None):
+        if ln is not None:
+            a = ops.linear(h, _fused_ln(self.net[0], "proj", ("proj",), ln[0], pair=True), ln_stats=ln[1], act=UR_ACT_GEGLU)
+        else:
+            a = ops.linear(h, self.net[0].proj.packed(pair=True), act=UR_ACT_GEGLU)     # a * gelu(g) in the epilogue
         return ops.linear(a, self.net[2].packed(), residual=residual)
 
 
@@ -288,9 +311,15 @@ class BasicTransformerBlock(nn.Module):
         self.norm3, self.ff = LayerNorm(c), FeedForward(c)
 
     def run(self, h, ctx):
-        h = self_attention(self.attn1, self.norm1.run(h), self.attn1.heads, h)
-        h = self.attn2.run_cross(self.norm2.run(h), ctx, h)
-        return self.ff.run(self.norm3.run(h), h)
+        st = ops.ln_of(h)
+        if st is None:                                  # no producer-side row sums: plain LayerNorm passes
+            h = self_attention(self.attn1, self.norm1.run(h), self.attn1.heads, h)
+            h = self.attn2.run_cross(self.norm2.run(h), ctx, h)
+            return self.ff.run(self.norm3.run(h), h)
+        # LayerNorm folded into the consuming GEMMs; each residual-producing GEMM leaves the next LN's row sums
+        h = self_attention(self.attn1, h, self.attn1.heads, h, ln=(self.norm1, st), rows=True)
+        h = self.attn2.run_cross(h, ctx, h, ln=(self.norm2, ops.ln_of(h)), rows=True)
+        return self.ff.run(h, h, ln=(self.norm3, ops.ln_of(h)))
 
 
 class Transformer2DModel(nn.Module):
@@ -303,7 +332,7 @@ class Transformer2DModel(nn.Module):
 
     def run(self, x, ctx):
         n, hh, ww, c = x.shape
-        h = ops.linear(self.norm.run(x).view(n, hh * ww, c), self.proj_in.packed())
+        h = ops.linear(self.norm.run(x).view(n, hh * ww, c), self.proj_in.packed(), rows=FUSE_LN)
         h = self.transformer_blocks[0].run(h, ctx)
         o = ops.linear(h, self.proj_out.packed(), residual=x.view(n, hh * ww, c), gn=True, gn_hw=(n, hh * ww))
         return ops.carry(o, o.view(n, hh, ww, c))

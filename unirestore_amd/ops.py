@@ -49,8 +49,8 @@ class StatsArena:
     """Bump allocator for the fp64 GroupNorm channel sums that conv epilogues produce (ur_conv_desc.gn_stats).
     One zero-fill of the used part per forward (`reset`) replaces a zero-fill per GroupNorm."""
 
-    def __init__(self, dev, n_doubles=48 << 20):
-        self.buf = torch.zeros(n_doubles, dtype=torch.float64, device=dev)
+    def __init__(self, dev, n_elems=48 << 20, dtype=torch.float64):
+        self.buf = torch.zeros(n_elems, dtype=dtype, device=dev)
         self.off = 0
         self.high = 0
 
@@ -81,14 +81,41 @@ class StatsArena:
         return v
 
 
+class _Arenas:
+    """fp64 channel-sum arena (GroupNorm) + fp32 row-sum arena (LayerNorm fusion); reset / mark / rewind act on both."""
+
+    def __init__(self, dev):
+        self.gn = StatsArena(dev)
+        self.rows = StatsArena(dev, 32 << 20, torch.float32)
+        self.off = 0          # kept for callers that poke the GroupNorm offset directly
+
+    def reset(self):
+        self.gn.reset(); self.rows.reset()
+
+    def mark(self):
+        return (self.gn.mark(), self.rows.mark())
+
+    def rewind(self, mark):
+        self.gn.rewind(mark[0])
+        self.rows.off = mark[1]          # row-sum partials are fully overwritten by their producers: no re-zeroing
+
+    def alloc(self, n):
+        return self.gn.alloc(n)
+
+
 _arena = {}
 
 
-def arena(dev=None) -> StatsArena:
+def arena(dev=None) -> _Arenas:
     dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else dev
     if dev not in _arena:
-        _arena[dev] = StatsArena(dev)
+        _arena[dev] = _Arenas(dev)
     return _arena[dev]
+
+
+def ln_of(t):
+    """Per-row (sum, sum of squares) attached to `t` by its producer GEMM (or None)."""
+    return getattr(t, "_ln", None)
 
 
 def gn_of(t):
@@ -101,6 +128,9 @@ def carry(src, dst):
     g = getattr(src, "_gn", None)
     if g is not None:
         dst._gn = g
+    r = getattr(src, "_ln", None)
+    if r is not None:
+        dst._ln = r
     return dst
 
 
@@ -120,6 +150,8 @@ class PackedConv:
     k: int            # kernel size (1 or 3)
     groups: int = 1
     pair: bool = False
+    ln_colsum: Optional[torch.Tensor] = None   # LayerNorm-fused GEMM: fp32 [cout] row sums of the folded bf16 weight
+    ln_eps: float = 0.0
     kcm: bool = False  # K order (64-ch chunk, tap, ch) instead of (tap, ch): consecutive K tiles re-read the same pixels (L2)
 
 
@@ -158,13 +190,13 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=F
     if kcm:
         wp = wp.reshape(cout_p, kh * kw, cin_p // 64, 64).permute(0, 2, 1, 3)
     return PackedConv(wp.reshape(cout_p, kh * kw * cin_p).to(BF16).contiguous(),
-                      None if b is None else b.contiguous(), cin_p, cout_p, cout_out, kh, groups, pair, kcm)
+                      None if b is None else b.contiguous(), cin_p, cout_p, cout_out, kh, groups, pair, kcm=kcm)
 
 
 # ------------------------------------------------------------------------------------------------ conv / gemm
 def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, act=UR_ACT_NONE, stride=1, pad=None,
          out_hw=None, upsample=False, out_f32=False, out_scale=1.0, out=None, yt=None, n_split=0, t_rows=0,
-         colsum=None, colsum_scale=1.0, gn=False):
+         colsum=None, colsum_scale=1.0, gn=False, rows=False, ln_stats=None):
     """x: [N,H,W,C1] bf16 (x2 optional [N,H,W,C2], virtual concat).  Returns [N,OH,OW,cout_out]."""
     assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
     n, h, w_, c1 = x.shape
@@ -191,9 +223,14 @@ def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, 
     if gn:      # the consumer of `out` is a GroupNorm: have the epilogue (or a fallback pass) leave its channel sums
         stats = arena(x.device).alloc(n * co_total * 2)
         d.gn_stats = stats.data_ptr()
+    if ln_stats is not None:
+        assert pc.ln_colsum is not None, "weights were not packed with pack_linear_ln"
+        st, parts = ln_stats
+        d.ln_stats, d.ln_colsum, d.ln_eps, d.ln_dim, d.ln_parts = st.data_ptr(), pc.ln_colsum.data_ptr(), pc.ln_eps, pc.cin, parts
     ws = workspace(x.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.N, d.H, d.W = n, h, w_
+    rstats = None
     d.C1, d.ldx, d.C2, d.ldx2 = (c1 // g if g > 1 else c1), c1, c2, c2
     d.Cout = pc.cout // g
     d.ldw = pc.w.shape[1]
@@ -211,10 +248,31 @@ def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, 
     if g > 1:
         d.bs_x, d.bs_w, d.bs_bias, d.bs_y = c1 // g, (pc.cout // g) * pc.w.shape[1], pc.cout // g, pc.cout_out // g
         d.bs_r = pc.cout_out // g
+    if rows:    # the consumer of `out` is a LayerNorm-fused GEMM: leave per-row (sum, sumsq) partials, one plane per N tile
+        parts = lib.ur_conv2d_row_stat_parts(d)
+        if parts <= 0:
+            check(parts if parts < 0 else -1)
+        rstats = (arena(x.device).rows.alloc(parts * n * oh * ow * 2), parts)
+        d.row_stats = rstats[0].data_ptr()
     check(lib.ur_conv2d_nhwc(d, _stream()))
     if stats is not None:
         out._gn = stats
+    if rstats is not None:
+        out._ln = rstats
     return out
+
+
+def pack_linear_ln(weight, bias, gamma, beta, eps, dev, *, pair=False) -> PackedConv:
+    """Linear(LayerNorm(x)) folded for the LN-fused GEMM epilogue: w' = W*gamma (bf16), bias' = W.beta + b,
+    ln_colsum[n] = sum_k bf16(w'[n,k]).  The kernel computes rstd*(w'.x - mean*ln_colsum) + bias'."""
+    w = weight.detach().to(dev, torch.float32)
+    g, b0 = gamma.detach().to(dev, torch.float32), beta.detach().to(dev, torch.float32)
+    wf = w * g[None, :]
+    t = w @ b0 + (bias.detach().to(dev, torch.float32) if bias is not None else 0.0)
+    pc = pack_conv(wf, t, dev, pair=pair)
+    pc.ln_colsum = pc.w.float().sum(dim=1).contiguous()          # in packed (possibly a|g interleaved) row order
+    pc.ln_eps = float(eps)
+    return pc
 
 
 def linear(x: torch.Tensor, pc: PackedConv, **kw):
@@ -226,6 +284,8 @@ def linear(x: torch.Tensor, pc: PackedConv, **kw):
         res = res.reshape(1, 1, rows, res.shape[-1])
     gn = kw.pop("gn", False)
     gn_hw = kw.pop("gn_hw", None)       # (N, HW): how the rows split into images for the fused GroupNorm sums
+    if kw.get("ln_stats") is None and getattr(pc, "ln_colsum", None) is not None:
+        raise ValueError("LayerNorm-folded weights need ln_stats")
     if gn:
         n_img, hw = gn_hw
         y = conv(x.reshape(n_img, 1, hw, shp[-1]), pc, residual=None if res is None else res.reshape(n_img, 1, hw, -1), gn=True, **kw)
