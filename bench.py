@@ -204,9 +204,18 @@ def main():
                       "gbs": round(v["bytes"] / sec / 1e9, 1) if v["bytes"] else None}
         dom = rep["conv3x3_igemm"]
         ach = dom["flops"] / (dom["ms"] / 1e3) / 1e12
-        result["roofline"] = {"kernel": "igemm_kernel (conv3x3 implicit GEMM, all launches of one forward)", "bound": "mfma",
-                              "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                              "traffic": None, "launches": dom["launches"], "avg_launch_us": fam["conv3x3_igemm"]["avg_us"]}
+        result["roofline"] = {"kernel": "conv3x3 implicit GEMM (igemm_halo_kernel + igemm fallbacks), all launches of one forward",
+                              "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": dom["launches"],
+                              "avg_launch_us": fam["conv3x3_igemm"]["avg_us"],
+                              "flops_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2), "flops_unit": "GFLOP"}
+        # HBM bytes of the most frequent launch of the family (conv3x3 320->320 @64x64, B=8: 140 launches per forward),
+        # from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE), committed file.
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_halo_conv.json")
+        if os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            result["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_note"] = pj["note"]
         result["families"] = fam
         result["profiled_forward_ms"] = round(sum(v["ms"] for v in rep.values()), 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

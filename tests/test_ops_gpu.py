@@ -291,7 +291,8 @@ def test_conv_halo_tile_path(ops, n, cin, cout, h, w, ups, res):
     assert rel_l2(st[..., 0], _nchw(y).double().sum((2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize("rows,c,n,pair", [(256, 320, 960, False), (300, 64, 128, False), (512, 320, 2560, True), (128, 640, 640, False)])
+@pytest.mark.parametrize("rows,c,n,pair", [(256, 320, 960, False), (300, 64, 128, False), (512, 320, 2560, True), (128, 640, 640, False),
+                                              (5200, 320, 2560, True)])      # last: >= 200 tiles of 256 x 256 -> gemm_glds_kernel
 def test_layernorm_fused_into_gemm(ops, rows, c, n, pair):
     """Producer GEMM leaves per-row sums; the consumer computes Linear(LayerNorm(x)) without a LayerNorm pass."""
     g = _gen(rows + n)
@@ -311,3 +312,15 @@ def test_layernorm_fused_into_gemm(ops, rows, c, n, pair):
         a, gt = ref.chunk(2, -1)
         ref = a * F.gelu(gt)
     assert rel_l2(y.float().cpu(), ref) < 6e-3      # gamma is folded into bf16 weights: one extra bf16 rounding of W*gamma
+
+
+@pytest.mark.parametrize("m,k,n,act", [(5200, 320, 2560, "geglu"), (8192, 192, 1792, "gate")])
+def test_linear_pair_act_256_tiles(ops, m, k, n, act):
+    """Large-N pair-activation GEMMs take the 256 x 256 pure-GEMM tile kernel (ragged M, K tail < 64)."""
+    g = _gen(m + n)
+    x = _rb(torch.randn(m, k, generator=g)); wt = _rb(torch.randn(n, k, generator=g) / math.sqrt(k)); b = torch.randn(n, generator=g)
+    a, gt = F.linear(x, wt, b).chunk(2, -1)
+    ref = a * F.gelu(gt) if act == "geglu" else a * gt
+    y = ops.linear(x.to(torch.bfloat16).cuda(), ops.pack_conv(wt, b, "cuda", pair=True),
+                   act=ops.UR_ACT_GEGLU if act == "geglu" else ops.UR_ACT_GATE)
+    assert y.shape == (m, n // 2) and rel_l2(y.float().cpu(), ref) < TOL_BF16

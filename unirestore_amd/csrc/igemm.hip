@@ -775,6 +775,127 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
 }
 
+// Pure-GEMM specialisation of the LDS-DMA ring (1x1 / Linear, single source): row base offsets are 32-bit element
+// offsets and nothing else is kept per row, which leaves room for 256 x 256 tiles (128 accumulator registers per wave).
+// Large-N GEMMs (GEGLU, fused QKV) are L2->CU ingest bound: at 128 x 128 tiles every flop costs 1/64 B of ingest,
+// at 256 x 256 half of that.
+template <int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
+  constexpr int NT = WM * WN * 64, RPP = NT / 8;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
+  constexpr int XP = BM / RPP, WP = BN / RPP, NLD = XP + WP;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && WTM % 32 == 0 && WTN % 32 == 0 && RPP % 16 == 0, "tile/wave shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid % WM, wn = wid / WM;
+  const int gb = blockIdx.y;
+  int id = blockIdx.x;
+  {
+    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
+  const uint16_t* __restrict__ Wt = p.w + gb * p.bs_w;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
+  int xoff[XP], woff[WP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) { const int m = m0 + i * RPP + lrow; xoff[i] = m < p.M ? m * p.ldx + chunk * 8 : -1; }
+#pragma unroll
+  for (int j = 0; j < WP; ++j) { const int r = n0 + j * RPP + lrow; woff[j] = r < p.Cout ? r * p.ldw + chunk * 8 : -1; }
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  int kbase = 0;
+  auto issue_tile = [&](int stage) {
+    unsigned char* xs = smem + stage * STAGE;
+    unsigned char* wsm = xs + BM * 128;
+    const bool kval = kbase + chunk * 8 < p.Ktot;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const uint16_t* g = (kval && xoff[i] >= 0) ? X1 + xoff[i] + kbase : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(xs + (i * RPP + wid * 8) * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const uint16_t* g = (kval && woff[j] >= 0) ? Wt + woff[j] + kbase : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wsm + (j * RPP + wid * 8) * 128), 16, 0, 0);
+    }
+    kbase += 64;
+  };
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int ntile = p.nk;
+  int issued = 0;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (issued < ntile) { issue_tile(s); ++issued; }
+  if (NST >= 3 && issued >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cs = 0, is = (NST - 1) % NST;
+  for (int t = 0; t < ntile; ++t) {
+    if (issued < ntile) { issue_tile(is); ++issued; is = (is + 1 == NST) ? 0 : is + 1; }
+    const unsigned char* xs = smem + cs * STAGE;
+    const unsigned char* wsm = xs + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int slot = ks * 2 + fhalf;
+      bf16x8 bfr[FM], afr[FN];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        const int row = wm * WTM + b * 32 + frow;
+        bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < FN; ++a) {
+        const int row = wn * WTN + a * 32 + frow;
+        afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+    cs = (cs + 1 == NST) ? 0 : cs + 1;
+    if (NST >= 3 && issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
+}
+
+template <int BM, int BN, int WM, int WN, int NST>
+int launch_gemm(ConvK& k, hipStream_t s) {
+  k.tiles_m = (k.M + BM - 1) / BM;
+  k.tiles_n = (k.Cout + BN - 1) / BN;
+  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
+  k.splitk = 1;
+  k.nk_per_split = k.nk;
+  k.gn_fused = k.gn_stats && k.staged_ok_ && (k.OHW % BM) == 0;
+  constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = BM * (BN * 2 + 8) + 7 * BN * 4 + BM * 8;
+  constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k);
+  return ur::check_launch("ur_conv2d_nhwc");
+}
+
 template <int BM, int BN, int WM, int WN, int NST>
 int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
   k.tiles_m = (k.M + BM - 1) / BM;
@@ -819,13 +940,14 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
 // K tile (3-stage ring).  Ingest per K tile drops from (256+BN)*128 B to ~BN*128 B + 5 KB.
 // A fragment is one 32-pixel patch row, so its LDS rows are consecutive for every tap and the (row>>1)&7 slot swizzle
 // stays conflict-free (tools/lds_conflicts.py model; a 16x16 patch would be 2-way conflicted on every tap).
-template <int BN, int WM, int WN>
-__global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
-  constexpr int BM = 256, TH = 8, TW = 32, PW = TW + 2, HPIX = (TH + 2) * PW;       // 340 halo pixels
-  constexpr int HPIECES = 48, HBYTES = HPIECES * 1024;   // 6 tap slots x 8 waves; pieces >= 43 are never read (zero fill)
-  constexpr int WBYTES = BN * 128, WPIECES = BN / 8, WPW = (WPIECES + 7) / 8;         // weight pieces per wave per tile
-  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = 512;
-  static_assert(WM * WN == 8 && WTM % 32 == 0 && WTN % 32 == 0, "8 waves");
+template <int TH, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) {
+  constexpr int NW = WM * WN, TW = 32, BM = TH * TW, PW = TW + 2, HPIX = (TH + 2) * PW;   // 340 (TH=8) / 204 (TH=4) halo pixels
+  constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);                              // tap slots that carry a halo piece
+  constexpr int HPIECES = HSLOTS * NW, HBYTES = HPIECES * 1024;   // surplus pieces are never read (zero fill)
+  constexpr int WBYTES = BN * 128, WPIECES = BN / 8, WPW = (WPIECES + NW - 1) / NW;   // weight pieces per wave per tile
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = NW * 64;
+  static_assert((NW == 8 || NW == 4) && WTM % 32 == 0 && WTN % 32 == 0 && HSLOTS <= 8, "wave layout");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const hbuf = smem;                      // 2 halo patches
   unsigned char* const wring = smem + 2 * HBYTES;        // 3 weight tiles
@@ -850,15 +972,15 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
   const uint16_t* __restrict__ Wt = p.w;
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
   const int lr = lane >> 3, ps = lane & 7;
-  // Every piece this wave issues has index == wid (mod 8), so its rows share one parity pattern and the lane's logical
+  // Every piece this wave issues has index == wid (mod NW, NW even), so its rows share one parity pattern and the lane's logical
   // 16-byte K chunk is the same for all of them: physical slot ps holds chunk ps ^ ((row>>1)&7), row = 8*piece + lr.
   const int chunk = ps ^ ((((wid & 1) << 2) + (lr >> 1)) & 7);
 
   // input-pixel index of this lane for the six halo pieces (tap slots 0..5) this wave issues per chunk; -1 = zero fill
-  int hpix[6];
+  int hpix[HSLOTS];
 #pragma unroll
-  for (int t = 0; t < 6; ++t) {
-    const int hr = (t * 8 + wid) * 8 + lr;
+  for (int t = 0; t < HSLOTS; ++t) {
+    const int hr = (t * NW + wid) * 8 + lr;
     const int hy = hr / PW, hx = hr - hy * PW;
     int iy = ty * TH - 1 + hy, ix = tx * TW - 1 + hx;               // coordinates in the (possibly upsampled) input
     const bool v = hr < HPIX && (unsigned)iy < (unsigned)p.OH && (unsigned)ix < (unsigned)p.OW;
@@ -868,7 +990,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
   int woff[WPW];
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
-    const int qq = (wid + 8 * i < WPIECES) ? wid + 8 * i : wid;       // surplus slot: repeat this wave's first piece
+    const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;     // surplus slot: repeat this wave's first piece
     const int row = n0 + qq * 8 + lr;
     woff[i] = row < p.Cout ? row * p.ldw : -1;
   }
@@ -878,13 +1000,13 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
     unsigned char* st = wring + (kt % 3) * WBYTES;
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-      const int qq = (wid + 8 * i < WPIECES) ? wid + 8 * i : wid;
+      const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
       const uint16_t* g = woff[i] >= 0 ? Wt + woff[i] + kt * 64 + chunk * 8 : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + qq * 1024), 16, 0, 0);
     }
   };
   auto issue_h = [&](int c, int t) {                                // halo piece (t*8 + wid) of chunk c
-    const int q = t * 8 + wid;
+    const int q = t * NW + wid;
     int cc = c * 64 + chunk * 8;
     const uint16_t* src = X1;
     int ld = p.ldx;
@@ -904,7 +1026,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
 
   // ---- prologue: whole halo of chunk 0, weight tiles 0 and 1 ------------------------------------------------------------
 #pragma unroll
-  for (int t = 0; t < 6; ++t) issue_h(0, t);
+  for (int t = 0; t < HSLOTS; ++t) issue_h(0, t);
   issue_w(0);
   if (nk > 1) {
     issue_w(1);
@@ -916,17 +1038,12 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
 
   for (int kt = 0, c = 0, tap = 0; kt < nk; ++kt) {
     const bool more_w = kt + 2 < nk;
-    const bool more_h = tap < 6 && c + 1 < nchunk;
+    const bool more_h = tap < HSLOTS && c + 1 < nchunk;
     if (more_w) issue_w(kt + 2);
     if (more_h) {
-      switch (tap) {                                                 // hpix[] must be indexed statically
-        case 0: issue_h(c + 1, 0); break;
-        case 1: issue_h(c + 1, 1); break;
-        case 2: issue_h(c + 1, 2); break;
-        case 3: issue_h(c + 1, 3); break;
-        case 4: issue_h(c + 1, 4); break;
-        default: issue_h(c + 1, 5); break;
-      }
+#pragma unroll
+      for (int t = 0; t < HSLOTS; ++t)                               // hpix[] must be indexed statically
+        if (tap == t) issue_h(c + 1, t);
     }
     // ---- MFMAs of K tile kt: B fragments = patch rows shifted by the tap, A fragments = weight tile -------------------
     {
@@ -965,12 +1082,13 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const ConvK p) {
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem);
 }
 
-template <int BN, int WM, int WN>
+template <int TH, int BN, int WM, int WN>
 int launch_halo(ConvK& k, hipStream_t s) {
-  constexpr int HBYTES = 48 * 1024;
-  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = 256 * (BN * 2 + 8) + 7 * BN * 4 + 256 * 8;
+  constexpr int NW = WM * WN, BM = TH * 32, HPIX = (TH + 2) * 34, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
+  constexpr int HBYTES = HSLOTS * NW * 1024;
+  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = BM * (BN * 2 + 8) + 7 * BN * 4 + BM * 8;
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  k.tiles_m = k.N * (k.OH / 8) * (k.OW / 32);
+  k.tiles_m = k.N * (k.OH / TH) * (k.OW / 32);
   k.tiles_n = (k.Cout + BN - 1) / BN;
   if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
   k.splitk = 1;
@@ -979,11 +1097,11 @@ int launch_halo(ConvK& k, hipStream_t s) {
   k.gn_fused = k.gn_stats != nullptr;                      // a patch never leaves its image
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN>), dim3(k.tiles_m * k.tiles_n), dim3(512), lds, s, k);
+  hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN>), dim3(k.tiles_m * k.tiles_n), dim3(NW * 64), lds, s, k);
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
@@ -993,10 +1111,21 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   if (!no_halo && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && k.staged_ok_ && !pair && k.nbatch == 1 &&
       k.OW % 32 == 0 && k.OH % 8 == 0 && k.OH == (k.ups ? 2 * k.H : k.H) && k.OW == (k.ups ? 2 * k.W : k.W) && !k.yt) {
     const bool n160h = k.Cout % 160 == 0 && k.Cout % 128 != 0;
-    const long long tiles = (long long)k.N * (k.OH / 8) * (k.OW / 32) * ((k.Cout + (n160h ? 159 : 127)) / (n160h ? 160 : 128));
-    if (tiles >= 128 && (n160h || k.Cout % 128 == 0)) {
-      if (n160h) return launch_halo<160, 8, 1>(k, s);
-      return launch_halo<128, 4, 2>(k, s);
+    const bool n160e = k.Cout % 160 == 0;                      // 160-wide tiles also divide 640 / 1280 / ...
+    const long long tiles8 = (long long)k.N * (k.OH / 8) * (k.OW / 32) * ((k.Cout + (n160h ? 159 : 127)) / (n160h ? 160 : 128));
+    static const bool no_h4 = getenv("UR_IGEMM_H4") == nullptr;   // opt-in: measured slightly slower (weight ingest per flop doubles)
+    if (tiles8 >= 224 && (n160h || k.Cout % 128 == 0)) {
+      if (n160h) return launch_halo<8, 160, 8, 1>(k, s);
+      return launch_halo<8, 128, 4, 2>(k, s);
+    }
+    // mid-size maps (e.g. 8 x 32x32): 8x32 patches leave CUs idle; 4x32 patches x 160 channels give >= one tile per CU
+    if (!no_h4 && k.OH % 4 == 0 && n160e) {
+      const long long tiles4 = (long long)k.N * (k.OH / 4) * (k.OW / 32) * (k.Cout / 160);
+      if (tiles4 >= 192) return launch_halo<4, 160, 4, 1>(k, s);
+    }
+    if (tiles8 >= 128 && (n160h || k.Cout % 128 == 0)) {
+      if (n160h) return launch_halo<8, 160, 8, 1>(k, s);
+      return launch_halo<8, 128, 4, 2>(k, s);
     }
   }
   static const int exp_mode = getenv("UR_IGEMM_EXP") ? atoi(getenv("UR_IGEMM_EXP")) : 0;
@@ -1004,6 +1133,10 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
     if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_glds<128, 160, 4, 1, 2>(k, s, 0);
     return launch_glds<128, 128, 2, 2, 2>(k, s, 0);
   }
+  static const bool no_g256 = getenv("UR_IGEMM_NOG256") != nullptr;
+  if (!no_g256 && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.staged_ok_ && k.Cout % 256 == 0 && !k.yt && (k.act == UR_ACT_GEGLU || k.act == UR_ACT_GATE) &&
+      (long long)((k.M + 255) / 256) * (k.Cout / 256) * k.nbatch >= 200 && (long long)k.M * k.ldx < (1ll << 31))
+    return launch_gemm<256, 256, 4, 2, 2>(k, s);
   static const bool force_v1 = getenv("UR_IGEMM_V1") != nullptr;
   // short-K GEMMs (<= 10 K tiles: per-workgroup prologue/epilogue latency dominates): 128-row tiles, 2 workgroups per CU
   const bool use_v1 = force_v1 || (k.KH == 1 && k.nk <= 10);
