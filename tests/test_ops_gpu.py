@@ -291,12 +291,15 @@ def test_conv_halo_tile_path(ops, n, cin, cout, h, w, ups, res):
     assert rel_l2(st[..., 0], _nchw(y).double().sum((2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize("rows,c,n,pair", [(256, 320, 960, False), (300, 64, 128, False), (512, 320, 2560, True), (128, 640, 640, False),
-                                              (5200, 320, 2560, True)])      # last: >= 200 tiles of 256 x 256 -> gemm_glds_kernel
-def test_layernorm_fused_into_gemm(ops, rows, c, n, pair):
+@pytest.mark.parametrize("rows,c,n,pair,k0", [
+    (256, 320, 960, False, 96), (300, 64, 128, False, 96), (512, 320, 2560, True, 96), (128, 640, 640, False, 96),
+    (5200, 320, 2560, True, 96),             # >= 200 tiles of 256 x 256 -> gemm_glds_kernel
+    (512, 1280, 1280, False, 1024),          # few tiles, long K: producer AND consumer go through split-K + the row-wise reduce
+    (200, 1280, 2560, True, 640), (2048, 1280, 1280, False, 96)])
+def test_layernorm_fused_into_gemm(ops, rows, c, n, pair, k0):
     """Producer GEMM leaves per-row sums; the consumer computes Linear(LayerNorm(x)) without a LayerNorm pass."""
     g = _gen(rows + n)
-    x0 = _rb(torch.randn(rows, 96, generator=g)); w0 = _rb(torch.randn(c, 96, generator=g) / 9); r0 = _rb(torch.randn(rows, c, generator=g) * 2 + 0.5)
+    x0 = _rb(torch.randn(rows, k0, generator=g)); w0 = _rb(torch.randn(c, k0, generator=g) / math.sqrt(k0)); r0 = _rb(torch.randn(rows, c, generator=g) * 2 + 0.5)
     ops.arena().reset()
     x = ops.linear(x0.to(torch.bfloat16).cuda(), ops.pack_conv(w0, None, "cuda"), residual=r0.to(torch.bfloat16).cuda(), rows=True)
     xs = x.float().cpu()

@@ -379,8 +379,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
         const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
         sx += a + b; sq += a * a + b * b;
       }
-      if (TPR == 2) { sx += __shfl_xor(sx, 1, 64); sq += __shfl_xor(sq, 1, 64); }
-      static_assert(TPR <= 2, "row-stat reduction assumes at most two threads per row");
+      if (TPR >= 2) { sx += __shfl_xor(sx, 1, 64); sq += __shfl_xor(sq, 1, 64); }
+      if (TPR >= 4) { sx += __shfl_xor(sx, 2, 64); sq += __shfl_xor(sq, 2, 64); }
+      static_assert(TPR == 1 || TPR == 2 || TPR == 4, "row-stat reduction: 1, 2 or 4 threads per row (same wave)");
       const int tn_idx = n0 / BN;
       if (m < p.M && part == 0)
         *reinterpret_cast<float2*>(p.row_stats + 2 * ((long long)tn_idx * p.M + m)) = make_float2(sx, sq);
@@ -574,14 +575,77 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p) {
   }
 }
 
+// Split-K reduce for GEMMs that take part in LayerNorm folding: one wave per output row, so the row owns its
+// LayerNorm statistics - the consumer transform rstd*(acc - mean*s[n]) is applied to the reduced sums, and the
+// producer's (sum, sumsq) of the bf16 values written goes out as ONE plane (ln_parts == 1 for the next GEMM).
+__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const ConvK p) {
+  const bool pair = is_pair_act(p.act);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int qn = p.Cout / 4;
+  for (int m = blockIdx.x * 4 + wv; m < p.M; m += gridDim.x * 4) {
+    float mean = 0.f, rstd = 1.f;
+    if (p.ln_stats) {
+      float sx = 0.f, sq = 0.f;
+      for (int q = 0; q < p.ln_parts; ++q) {
+        const float2 t2 = *reinterpret_cast<const float2*>(p.ln_stats + 2 * ((long long)q * p.M + m));
+        sx += t2.x; sq += t2.y;
+      }
+      mean = sx / p.ln_dim;
+      rstd = rsqrtf(fmaxf(sq / p.ln_dim - mean * mean, 0.f) + p.ln_eps);
+    }
+    float rsx = 0.f, rsq = 0.f;
+    for (int q = lane; q < qn; q += 64) {
+      const int co_in = q * 4;
+      if (pair && (co_in & 32)) continue;
+      float v[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+      for (int s = 0; s < p.splitk; ++s) {
+        const float* ws = p.ws + ((long long)s * p.M + m) * p.Cout + co_in;
+        const float4 t = *reinterpret_cast<const float4*>(ws);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        if (pair) {
+          const float4 u = *reinterpret_cast<const float4*>(ws + 32);
+          g[0] += u.x; g[1] += u.y; g[2] += u.z; g[3] += u.w;
+        }
+      }
+      if (p.ln_stats) {
+        const float4 sc = *reinterpret_cast<const float4*>(p.ln_colsum + co_in);
+        v[0] = rstd * (v[0] - mean * sc.x); v[1] = rstd * (v[1] - mean * sc.y);
+        v[2] = rstd * (v[2] - mean * sc.z); v[3] = rstd * (v[3] - mean * sc.w);
+        if (pair) {
+          const float4 sg = *reinterpret_cast<const float4*>(p.ln_colsum + co_in + 32);
+          g[0] = rstd * (g[0] - mean * sg.x); g[1] = rstd * (g[1] - mean * sg.y);
+          g[2] = rstd * (g[2] - mean * sg.z); g[3] = rstd * (g[3] - mean * sg.w);
+        }
+      }
+      const int co = epi_act(p, 0, m, co_in, v, g);
+      if (p.res) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + (long long)m * p.ldr + co);
+        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+      }
+      const uint2 o = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.ldy + co) = o;
+      const float a0 = __uint_as_float(o.x << 16), a1 = __uint_as_float(o.x & 0xffff0000u);
+      const float a2 = __uint_as_float(o.y << 16), a3 = __uint_as_float(o.y & 0xffff0000u);
+      rsx += (a0 + a1) + (a2 + a3);
+      rsq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    if (p.row_stats) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { rsx += __shfl_xor(rsx, o, 64); rsq += __shfl_xor(rsq, o, 64); }
+      if (lane == 0) *reinterpret_cast<float2*>(p.row_stats + 2 * (long long)m) = make_float2(rsx, rsq);
+    }
+  }
+}
+
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.Cout + BN - 1) / BN;
-  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
   const long long blocks = (long long)k.tiles_m * k.tiles_n * k.nbatch;
   int splitk = 1;
-  if (blocks < 200 && k.nk >= 8 && k.ws && !k.row_stats && !k.ln_stats) {
+  if (blocks < 200 && k.nk >= 8 && k.ws) {
     long long want = (384 + blocks - 1) / blocks;
     long long cap_k = k.nk / 4;
     splitk = (int)std::min<long long>(std::min<long long>(want, cap_k), 16);
@@ -592,6 +656,7 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   k.splitk = splitk;
   k.nk_per_split = (k.nk + splitk - 1) / splitk;
   k.splitk = (k.nk + k.nk_per_split - 1) / k.nk_per_split;
+  if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }     // row-stat planes this launch writes
   k.gn_fused = k.gn_stats && k.staged_ok_ && k.splitk == 1 && BN >= 32 && (k.OHW % BM) == 0;
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
@@ -603,9 +668,13 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, k);
   if (k.splitk > 1) {
-    long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
-    int rb = (int)std::min<long long>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
+    if (k.row_stats || k.ln_stats) {
+      hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(std::min((k.M + 3) / 4, 4096)), dim3(256), 0, s, k);
+    } else {
+      long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
+      int rb = (int)std::min<long long>((total + 255) / 256, 2048);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
+    }
   }
   return ur::check_launch("ur_conv2d_nhwc");
 }
@@ -1128,6 +1197,18 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
       return launch_halo<8, 128, 4, 2>(k, s);
     }
   }
+  static const int sm_exp = getenv("UR_IGEMM_SM") ? atoi(getenv("UR_IGEMM_SM")) : 0;
+  if (sm_exp && !pair && k.KH == 1 && k.Cout % 128 == 0) {
+    if (sm_exp == 1) { k.ws = nullptr; return launch_cfg<128, 128, 2, 2>(k, s); }
+    if (sm_exp == 2) return launch_cfg<64, 128, 2, 2>(k, s);
+    if (sm_exp == 3) return launch_glds<64, 128, 2, 2, 3>(k, s, 0);
+    if (sm_exp == 4) return launch_glds<128, 128, 2, 2, 3>(k, s, 0);
+    if (sm_exp == 5) return launch_cfg<64, 64, 2, 2>(k, s);
+    if (sm_exp == 6) return launch_glds<64, 128, 2, 2, 4>(k, s, 0);
+    if (sm_exp == 7) return launch_glds<64, 64, 2, 2, 4>(k, s, 0);
+    if (sm_exp == 8 && k.Cout % 160 == 0) return launch_cfg<128, 160, 4, 1>(k, s);
+    if (sm_exp == 9) return launch_cfg<128, 64, 2, 2>(k, s);
+  }
   static const int exp_mode = getenv("UR_IGEMM_EXP") ? atoi(getenv("UR_IGEMM_EXP")) : 0;
   if (exp_mode && k.KH == 1 && k.nk <= exp_mode && !pair && k.Cout > 64) {      // short-K GEMMs: 2 workgroups per CU
     if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_glds<128, 160, 4, 1, 2>(k, s, 0);
@@ -1140,6 +1221,14 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   static const bool force_v1 = getenv("UR_IGEMM_V1") != nullptr;
   // short-K GEMMs (<= 10 K tiles: per-workgroup prologue/epilogue latency dominates): 128-row tiles, 2 workgroups per CU
   const bool use_v1 = force_v1 || (k.KH == 1 && k.nk <= 10);
+  const long long blocks128 = (long long)((k.M + 127) / 128) * ((k.Cout + 127) / 128) * k.nbatch;
+  static const bool no_t64 = getenv("UR_IGEMM_NOT64") != nullptr;
+  if (!no_t64 && k.KH == 1 && !pair && k.Cout > 64) {
+    // too few 128 x 128 tiles to fill 256 CUs and K too short for split-K to pay for its reduce pass: 64 x 64 tiles
+    if (blocks128 < 200 && k.nk <= 24) return launch_cfg<64, 64, 2, 2>(k, s);
+    // 1 < tiles/CU < 2 at 128 x 128: halve the N tile so every CU gets the same work
+    if (use_v1 && blocks128 > 256 && blocks128 < 400 && k.Cout % 128 == 0) return launch_cfg<128, 64, 2, 2>(k, s);
+  }
   if (use_v1) {
     if (pair) return launch_cfg<128, 128, 2, 2>(k, s);  // a|g 32-row blocks must sit in one wave tile
     if (k.Cout <= 32) return launch_cfg<256, 32, 4, 1>(k, s);
