@@ -257,14 +257,17 @@ def test_conv_per_image_bias(ops):
     assert rel_l2(_nchw(y), F.conv2d(x, wt, padding=1) + bi[:, :, None, None]) < TOL_BF16
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w,k", [(2, 64, 128, 16, 16, 3), (8, 320, 320, 16, 16, 3), (2, 64, 64, 8, 8, 1), (1, 128, 256, 24, 8, 1)])
+@pytest.mark.parametrize("n,cin,cout,h,w,k", [(2, 64, 128, 16, 16, 3), (8, 320, 320, 16, 16, 3), (2, 64, 64, 8, 8, 1), (1, 128, 256, 24, 8, 1),
+                                               (2, 1280, 640, 16, 16, 3), (3, 640, 1280, 8, 8, 3)])      # last two: split-K reduce leaves the sums
 def test_conv_fused_groupnorm_stats(ops, n, cin, cout, h, w, k):
     """The conv epilogue (or its fallback pass) leaves per-image channel sums; GroupNorm consumes them without a stats pass."""
     g = _gen(cout + h)
     x = _rb(torch.randn(n, cin, h, w, generator=g)); wt = _rb(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k))
     b = torch.randn(cout, generator=g); ga, be = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
     ops.arena().reset()
-    y = ops.conv(_nhwc(x), ops.pack_conv(wt, b, "cuda"), gn=True)
+    r = _rb(torch.randn(n, cout, h, w, generator=g))
+    y = ops.conv(_nhwc(x), ops.pack_conv(wt, b, "cuda"), gn=True, residual=_nhwc(r))
+    assert rel_l2(_nchw(y), F.conv2d(x, wt, b, padding=k // 2) + r) < TOL_BF16
     st = ops.gn_of(y).view(n, cout, 2).cpu()
     yf = _nchw(y).double()
     assert rel_l2(st[..., 0], yf.sum((2, 3))) < 1e-5 and rel_l2(st[..., 1], (yf * yf).sum((2, 3))) < 1e-5

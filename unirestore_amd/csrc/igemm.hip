@@ -639,6 +639,77 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const ConvK p) 
 }
 
 
+// Split-K reduce that also leaves the GroupNorm statistics of what it writes (the 16x16 / 8x8 levels: every 3x3 conv
+// there is split-K, and each used to be followed by a separate statistics pass).  Block = 16 column quads x 16 row
+// lanes over 64 consecutive rows of ONE image (host guarantees OHW % 64 == 0); column sums stay in registers, the
+// row lanes meet in LDS, then one fp64 atomic per (column, moment) per block.
+__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
+  __shared__ float red[16][16][9];
+  const int qc = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int q = blockIdx.x * 16 + qc, qn = p.Cout / 4, co = q * 4;
+  const int r0 = blockIdx.y * 64;
+  float sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+  if (q < qn) {
+    float v[4][4];
+    uint2 rv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = r0 + rl + 16 * i;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+      for (int sp = 0; sp < p.splitk; ++sp) {
+        const float4 t = *reinterpret_cast<const float4*>(p.ws + ((long long)sp * p.M + m) * p.Cout + co);
+        v[i][0] += t.x; v[i][1] += t.y; v[i][2] += t.z; v[i][3] += t.w;
+      }
+      rv[i] = p.res ? *reinterpret_cast<const uint2*>(p.res + (long long)m * p.ldr + co) : make_uint2(0, 0);
+    }
+    const float g[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = r0 + rl + 16 * i;
+      epi_act(p, 0, m, co, v[i], g);
+      v[i][0] += __uint_as_float(rv[i].x << 16); v[i][1] += __uint_as_float(rv[i].x & 0xffff0000u);
+      v[i][2] += __uint_as_float(rv[i].y << 16); v[i][3] += __uint_as_float(rv[i].y & 0xffff0000u);
+      const uint2 o = make_uint2(pack2bf(v[i][0], v[i][1]), pack2bf(v[i][2], v[i][3]));
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.ldy + co) = o;
+      const float a[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
+                          __uint_as_float(o.y & 0xffff0000u)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sm[e] += a[e]; sq[e] += a[e] * a[e]; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[rl][qc][e] = sm[e]; red[rl][qc][4 + e] = sq[e]; }
+  __syncthreads();
+  // 128 (column quad, moment-lane) sums of 16 row lanes each, then one fp64 atomic per (column, moment)
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x >> 3, e = threadIdx.x & 7;
+    const int qq = blockIdx.x * 16 + c;
+    if (qq < qn) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += red[r][c][e];
+      double* st = p.gn_stats + ((long long)(r0 / p.OHW) * p.Cout + qq * 4) * 2;
+      atomicAdd(&st[2 * (e & 3) + (e >> 2)], (double)a);
+    }
+  }
+}
+
+// picks the reduce pass of a split-K launch (and records whether it produced the GroupNorm statistics)
+static void launch_splitk_reduce(ConvK& k, hipStream_t s) {
+  const bool pair = k.act == UR_ACT_GEGLU || k.act == UR_ACT_GATE;
+  if (k.row_stats || k.ln_stats) {
+    hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(std::min((k.M + 3) / 4, 4096)), dim3(256), 0, s, k);
+  } else if (!getenv("UR_IGEMM_NOGNRED") && k.gn_stats && !pair && k.staged_ok_ && k.nbatch == 1 && !k.yt && k.OHW % 64 == 0 && !k.patch_tw) {
+    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((k.Cout / 4 + 15) / 16, k.M / 64), dim3(256), 0, s, k);
+    k.gn_fused = 1;
+  } else {
+    long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
+    int rb = (int)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
@@ -667,15 +738,7 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, k);
-  if (k.splitk > 1) {
-    if (k.row_stats || k.ln_stats) {
-      hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(std::min((k.M + 3) / 4, 4096)), dim3(256), 0, s, k);
-    } else {
-      long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
-      int rb = (int)std::min<long long>((total + 255) / 256, 2048);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
-    }
-  }
+  if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
@@ -990,11 +1053,7 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
   hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, WM, WN, NST>), grid, dim3(WM * WN * 64), lds, s, k);
-  if (k.splitk > 1) {
-    long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
-    int rb = (int)std::min<long long>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
-  }
+  if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
