@@ -156,6 +156,16 @@ int ur_nhwc_to_nchw_f32(const void* x, int x_is_f32, float* out, int N, int C, i
                         float add, ur_stream_t stream);
 /* NCHW fp32 -> NHWC bf16 with channel padding (module-level API plumbing) */
 int ur_nchw_f32_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, ur_stream_t stream);
+/* DiffUIE.forward pre-processing (reference unifie.py:124-134) fused with the encoder's x*2-1 (autoencoder.py:152 -> vae.encode)
+ * and the NHWC layout pass: img fp32 [N,C,H,W] -> F.interpolate(bicubic, align_corners=False, antialias=False) to RH x RW
+ * (skipped when equal) -> F.pad(reflect) right/bottom by PW/PH -> v*mul+add -> y bf16 [N,RH+PH,RW+PW,Cpad]. */
+int ur_image_resize_pad_nhwc(const float* img, void* y, int N, int C, int H, int W, int RH, int RW, int PH, int PW, int Cpad,
+                             float mul, float add, ur_stream_t stream);
+/* DiffUIE.forward post-processing (unifie.py:164-168) and the evaluator's 8-bit quantisation (eval_image_restoration.py:71):
+ * x NHWC (bf16 | fp32) [N,XH,XW,ld] -> v*mul+add -> crop [0:CH,0:CW] -> bicubic to OH x OW -> optional
+ * mul(255).round().clamp(0,255).div(255) -> out fp32 [N,C,OH,OW]. */
+int ur_image_unpad_resize_nchw(const void* x, int x_is_f32, float* out, int N, int C, int XH, int XW, int ld, int CH, int CW,
+                               int OH, int OW, float mul, float add, int quantize, ur_stream_t stream);
 /* z = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale; moments NHWC fp32 [M, ld] (mean | logvar) */
 int ur_vae_sample(const float* moments, int ld, const float* noise_nchw, float* z_nhwc, void* z_bf16, int N,
                   int HW, int Clat, int Cpad, float scale, ur_stream_t stream);

@@ -128,3 +128,27 @@ def test_reference_error_behaviour(M):
         M.SkipConnectedAutoEncoder(M.AutoencoderKL(**TINY["vae_cfg"]), None, dict(type="nope", task=["ir"], prompt_len=1))
     with pytest.raises(ValueError):
         M.ControlledUNet(M.UNet2DConditionModel(**TINY["unet_cfg"]), "bogus")
+
+
+def test_runner_validation_step_quantised(M):
+    """Caller side (LitUniFIE.forward + evaluator crop / 8-bit quantisation): crop -> restore -> values on the 1/255 grid,
+    equal to quantising the un-quantised forward (up to rounding ties of the bicubic output)."""
+    from unirestore_amd import runner
+    _, p = _pair(M, 5, steps=1)
+    g = torch.Generator().manual_seed(11)
+    assert runner.crop_tensor(torch.rand(1, 3, 520, 90, generator=g)).shape == (1, 3, 512, 90)
+    small = torch.rand(1, 3, 72, 64, generator=g)
+    from unirestore_amd.modules.model import resize_pad_plan
+    h, w, ph, pw = resize_pad_plan(72, 64)
+    nz = (torch.randn(1, 4, (h + ph) // 8, (w + pw) // 8, generator=g), torch.randn(1, 4, (h + ph) // 8, (w + pw) // 8, generator=g))
+    plain = p(small, "ir", noise=nz).cpu()
+    q = p(small, "ir", noise=nz, quantize=True).cpu()
+    assert q.shape == small.shape
+    assert float((q * 255 - (q * 255).round()).abs().max()) < 1e-3
+    d = (q - plain.mul(255).round().clamp(0, 255).div(255)).abs()
+    # the two forwards are separate runs of a bf16 pipeline with atomically-ordered sums: code values may move by one step
+    assert d.max() <= 2 / 255 + 1e-6 and float(d.mean()) < 1 / 255      # (the kernel itself is checked exactly in test_ops_gpu)
+    preds, _ = runner.validation_step(p, small, need_crop=True)
+    assert len(preds) == 1 and preds[0].shape == small.shape and 0.0 <= float(preds[0].min()) and float(preds[0].max()) <= 1.0
+    with pytest.raises(ValueError):
+        p(small, "ir", noise=(nz[0][..., :-1], nz[1]))

@@ -330,3 +330,34 @@ def test_linear_pair_act_256_tiles(ops, m, k, n, act):
     y = ops.linear(x.to(torch.bfloat16).cuda(), ops.pack_conv(wt, b, "cuda", pair=True),
                    act=ops.UR_ACT_GEGLU if act == "geglu" else ops.UR_ACT_GATE)
     assert y.shape == (m, n // 2) and rel_l2(y.float().cpu(), ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("h,w,rh,rw,ph,pw", [(37, 53, 90, 131, 6, 29), (64, 96, 40, 60, 24, 4), (48, 48, 48, 48, 16, 16), (33, 47, 33, 47, 0, 0)])
+def test_image_resize_reflect_pad(ops, h, w, rh, rw, ph, pw):
+    """unifie.py:124-134 as one HIP kernel: bicubic (align_corners=False, no antialias) + reflect pad + x*2-1 + NHWC bf16."""
+    img = torch.rand(2, 3, h, w, generator=_gen(h * w))
+    ref = F.interpolate(img, (rh, rw), mode="bicubic", align_corners=False, antialias=False) if (rh, rw) != (h, w) else img
+    if ph or pw:
+        ref = F.pad(ref, (0, pw, 0, ph), mode="reflect")
+    ref = ref * 2 - 1
+    y = ops.image_resize_pad(img.cuda(), rh, rw, ph, pw)
+    assert y.shape == (2, rh + ph, rw + pw, 8) and float(y[..., 3:].float().abs().max()) == 0.0
+    got = y[..., :3].float().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max() < 8e-3 and rel_l2(got, ref) < TOL_BF16          # one bf16 rounding of values in [-1.3, 1.3]
+
+
+@pytest.mark.parametrize("f32", [True, False])
+@pytest.mark.parametrize("xh,xw,ch,cw,oh,ow", [(24, 40, 20, 33, 37, 53), (64, 64, 64, 50, 32, 25), (16, 24, 16, 24, 16, 24)])
+def test_image_unpad_resize_quantize(ops, f32, xh, xw, ch, cw, oh, ow):
+    """unifie.py:164-168 (+ the evaluator's 8-bit quantisation, eval_image_restoration.py:71) as one HIP kernel."""
+    x = torch.randn(2, xh, xw, 8, generator=_gen(xh + ow)) * 0.6
+    x = x if f32 else _rb(x)
+    xd = (x if f32 else x.to(torch.bfloat16)).cuda()
+    ref = (x[..., :3] * 0.5 + 0.5)[:, :ch, :cw].permute(0, 3, 1, 2)
+    ref = F.interpolate(ref, (oh, ow), mode="bicubic", align_corners=False, antialias=False)
+    got = ops.image_unpad_resize(xd, 3, (ch, cw), (oh, ow), mul=0.5, add=0.5).cpu()
+    assert got.shape == ref.shape and (got - ref).abs().max() < 2e-5
+    q = ops.image_unpad_resize(xd, 3, (ch, cw), (oh, ow), mul=0.5, add=0.5, quantize=True).cpu()
+    qref = ref.mul(255).round().clamp(0, 255).div(255)
+    d = (q - qref).abs()
+    assert d.max() <= 1.0 / 255 + 1e-6 and float((d > 1e-6).float().mean()) < 2e-3     # a rounding tie may flip one code value

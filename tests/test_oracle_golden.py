@@ -107,3 +107,20 @@ def test_resize_pad_crop_integer_kats():
     assert resize_pad_plan(720, 1280) == (720, 1280, 48, 0)
     assert center_crop_box(720, 1280) == (104, 616, 384, 896)
     assert center_crop_box(300, 500) == (0, 300, 0, 500)
+
+
+def test_caller_side_crop_arithmetic():
+    """crop_tensor window + resize/pad plan KATs from SURVEY.md 8(c): the integer arithmetic either side of the path."""
+    import torch
+    from oracle.model import center_crop_box, resize_pad_plan
+    from unirestore_amd import runner
+    from unirestore_amd.modules.model import resize_pad_plan as rp_hip
+    for h, w in [(720, 1280), (512, 512), (300, 500), (513, 1023), (100, 2000), (511, 511)]:
+        assert runner.crop_box(h, w) == center_crop_box(h, w)
+        assert rp_hip(h, w) == resize_pad_plan(h, w)
+    assert runner.crop_box(720, 1280) == (104, 616, 384, 896)
+    assert runner.crop_tensor(torch.zeros(1, 3, 720, 1280)).shape == (1, 3, 512, 512)
+    assert runner.crop_tensor(torch.zeros(3, 513, 300)).shape == (3, 512, 300)
+    assert resize_pad_plan(256, 256) == (512, 512, 0, 0)
+    assert resize_pad_plan(300, 500) == (512, 853, 0, 43)
+    assert resize_pad_plan(720, 1280) == (720, 1280, 48, 0)

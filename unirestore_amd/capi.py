@@ -58,6 +58,8 @@ SIGNATURES = {
     "ur_image_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ur_nhwc_to_nchw_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     "ur_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ur_image_resize_pad_nhwc": (_I, [_P, _P] + [_I] * 9 + [_F, _F, _P]),
+    "ur_image_unpad_resize_nchw": (_I, [_P, _I, _P] + [_I] * 9 + [_F, _F, _I, _P]),
     "ur_vae_sample": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ur_add_noise": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "ur_ddim_step": (_I, [_P, _P, _I, _P, _LL, _I, _I, _F, _F, _P]),

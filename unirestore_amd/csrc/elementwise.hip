@@ -198,6 +198,93 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
   }
 }
 
+// ---- image boundary: bicubic resize (PyTorch semantics: A = -0.75, align_corners=False, antialias=False, source
+// index NOT clamped for cubic, tap indices clamped to the image) fused with reflect pad / crop and the layout pass ----
+__device__ __forceinline__ void cubic_taps(int dst, float scale, int in_size, int idx[4], float wt[4]) {
+  const float real = scale * (dst + 0.5f) - 0.5f;          // upsample_bicubic2d: area_pixel_compute_source_index(cubic=true)
+  const float fl = floorf(real);
+  const float t = fminf(fmaxf(real - fl, 0.f), 1.f);
+  const int i0 = (int)fl;
+  const float A = -0.75f;
+  const float x1 = t, x2 = 1.f - t;
+  wt[0] = ((A * (x1 + 1.f) - 5.f * A) * (x1 + 1.f) + 8.f * A) * (x1 + 1.f) - 4.f * A;
+  wt[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+  wt[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  wt[3] = ((A * (x2 + 1.f) - 5.f * A) * (x2 + 1.f) + 8.f * A) * (x2 + 1.f) - 4.f * A;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) idx[j] = max(min(i0 + j - 1, in_size - 1), 0);
+}
+
+// img [N,C,H,W] fp32 -> (bicubic to RH x RW) -> reflect pad right/bottom -> v*mul+add -> y bf16 [N,RH+PH,RW+PW,Cpad]
+__global__ __launch_bounds__(256) void image_resize_pad_kernel(const float* __restrict__ img, uint16_t* __restrict__ y, int C,
+                                                               int H, int W, int RH, int RW, int PH, int PW, int Cpad,
+                                                               float mul, float add, long long total) {
+  const int OH = RH + PH, OW = RW + PW;
+  const bool resize = RH != H || RW != W;
+  const float sh = (float)H / RH, sw = (float)W / RW;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % OW);
+    const long long r = i / OW;
+    const int oy = (int)(r % OH), n = (int)(r / OH);
+    const int ry = oy < RH ? oy : 2 * (RH - 1) - oy, rx = ox < RW ? ox : 2 * (RW - 1) - ox;   // F.pad(mode="reflect")
+    const float* base = img + (long long)n * C * H * W;
+    uint16_t* yo = y + i * Cpad;
+    if (!resize) {
+      for (int c = 0; c < Cpad; ++c) yo[c] = c < C ? f2bf(base[((long long)c * H + ry) * W + rx] * mul + add) : (uint16_t)0;
+      continue;
+    }
+    int iy[4], ix[4];
+    float wy[4], wx[4];
+    cubic_taps(ry, sh, H, iy, wy);
+    cubic_taps(rx, sw, W, ix, wx);
+    for (int c = 0; c < Cpad; ++c) {
+      float v = 0.f;
+      if (c < C) {
+        const float* pc = base + (long long)c * H * W;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float* row = pc + (long long)iy[a] * W;
+          v += wy[a] * (wx[0] * row[ix[0]] + wx[1] * row[ix[1]] + wx[2] * row[ix[2]] + wx[3] * row[ix[3]]);
+        }
+      }
+      yo[c] = c < C ? f2bf(v * mul + add) : (uint16_t)0;
+    }
+  }
+}
+
+// x NHWC (bf16 | fp32) [N,XH,XW,ld] -> v*mul+add -> crop [0:CH, 0:CW] -> bicubic to OH x OW -> optional
+// mul(255).round().clamp(0,255).div(255) -> out fp32 [N,C,OH,OW]
+__global__ __launch_bounds__(256) void image_unpad_resize_kernel(const void* __restrict__ x, int is_f32, float* __restrict__ out,
+                                                                 int C, int XH, int XW, int ld, int CH, int CW, int OH, int OW,
+                                                                 float mul, float add, int quantize, long long total) {
+  const bool resize = OH != CH || OW != CW;
+  const float sh = (float)CH / OH, sw = (float)CW / OW;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % OW);
+    const long long r = i / OW;
+    const int oy = (int)(r % OH), n = (int)(r / OH);
+    int iy[4] = {oy, 0, 0, 0}, ix[4] = {ox, 0, 0, 0};
+    float wy[4] = {1.f, 0.f, 0.f, 0.f}, wx[4] = {1.f, 0.f, 0.f, 0.f};
+    if (resize) { cubic_taps(oy, sh, CH, iy, wy); cubic_taps(ox, sw, CW, ix, wx); }
+    const long long nb = (long long)n * XH * XW;
+    for (int c = 0; c < C; ++c) {
+      float v = 0.f;
+      const int taps = resize ? 4 : 1;
+      for (int a = 0; a < taps; ++a) {
+        float rowv = 0.f;
+        for (int b = 0; b < taps; ++b) {
+          const long long e = (nb + (long long)iy[a] * XW + ix[b]) * ld + c;
+          const float t = is_f32 ? reinterpret_cast<const float*>(x)[e] : bf2f(reinterpret_cast<const uint16_t*>(x)[e]);
+          rowv += wx[b] * (t * mul + add);
+        }
+        v += wy[a] * rowv;
+      }
+      if (quantize) v = fminf(fmaxf(rintf(v * 255.f), 0.f), 255.f) / 255.f;     // torch.round = half-to-even = rintf
+      out[(((long long)n * C + c) * OH + oy) * OW + ox] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void vae_sample_kernel(const float* __restrict__ mom, int ld, const float* __restrict__ noise,
                                                          float* __restrict__ z, uint16_t* __restrict__ zb, long long HW,
                                                          int Clat, int Cpad, float scale, long long total) {
@@ -348,6 +435,26 @@ int ur_nhwc_to_nchw_f32(const void* x, int x_is_f32, float* out, int N, int C, i
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, x_is_f32, out, C,
                      (long long)H * W, ld, mul, add, total);
   return ur::check_launch("ur_nhwc_to_nchw_f32");
+}
+
+int ur_image_resize_pad_nhwc(const float* img, void* y, int N, int C, int H, int W, int RH, int RW, int PH, int PW, int Cpad,
+                             float mul, float add, ur_stream_t stream) {
+  UR_REQUIRE(img && y && Cpad >= C && N > 0 && H > 0 && W > 0 && RH > 0 && RW > 0, "bad args");
+  UR_REQUIRE(PH >= 0 && PW >= 0 && PH < RH && PW < RW, "reflect padding must be smaller than the image");
+  const long long total = (long long)N * (RH + PH) * (RW + PW);
+  hipLaunchKernelGGL(image_resize_pad_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, img, (uint16_t*)y, C, H, W,
+                     RH, RW, PH, PW, Cpad, mul, add, total);
+  return ur::check_launch("ur_image_resize_pad_nhwc");
+}
+
+int ur_image_unpad_resize_nchw(const void* x, int x_is_f32, float* out, int N, int C, int XH, int XW, int ld, int CH, int CW,
+                               int OH, int OW, float mul, float add, int quantize, ur_stream_t stream) {
+  UR_REQUIRE(x && out && ld >= C && N > 0 && OH > 0 && OW > 0, "bad args");
+  UR_REQUIRE(CH > 0 && CW > 0 && CH <= XH && CW <= XW, "crop window must lie inside the input");
+  const long long total = (long long)N * OH * OW;
+  hipLaunchKernelGGL(image_unpad_resize_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, x_is_f32, out, C, XH, XW,
+                     ld, CH, CW, OH, OW, mul, add, quantize, total);
+  return ur::check_launch("ur_image_unpad_resize_nchw");
 }
 
 int ur_vae_sample(const float* moments, int ld, const float* noise_nchw, float* z_nhwc, void* z_bf16, int N, int HW,

@@ -202,10 +202,12 @@ class SkipConnectedAutoEncoder(nn.Module):
             self.task_list, self.tedit_type = [], None
 
     # ---- NHWC fast path -------------------------------------------------------------------------------------
-    def encode_run(self, images_dev: torch.Tensor, noise_nchw: torch.Tensor, enable_fr: bool):
-        """images fp32 NCHW in [0,1] on device -> (z fp32 [B,h,w,8], z bf16, [3 NHWC bf16 skip features])."""
+    def encode_run(self, images_dev: torch.Tensor, noise_nchw: torch.Tensor, enable_fr: bool, plan=None):
+        """images fp32 NCHW in [0,1] on device -> (z fp32 [B,h,w,8], z bf16, [3 NHWC bf16 skip features]).
+        plan = (resized_h, resized_w, pad_h, pad_w): DiffUIE.forward's bicubic resize + reflect pad run in the layout kernel."""
         enc, lat = self.vae.encoder, self.vae.latent_channels
-        h = ops.conv(ops.nchw_to_nhwc(images_dev, image=True), enc.conv_in.packed(), gn=True)   # x*2-1 fused in the layout pass
+        x0 = ops.image_resize_pad(images_dev, *plan) if plan else ops.nchw_to_nhwc(images_dev, image=True)   # x*2-1 fused
+        h = ops.conv(x0, enc.conv_in.packed(), gn=True)
         res = []
         for i, blk in enumerate(enc.down_blocks[:-1]):
             h = blk.run(h)
@@ -218,7 +220,8 @@ class SkipConnectedAutoEncoder(nn.Module):
         z, zb = ops.vae_sample(moments, noise_nchw, lat, self.vae.config.scaling_factor)
         return z, zb, res
 
-    def decode_run(self, z_f32: torch.Tensor, res_samples, task: str):
+    def decode_run(self, z_f32: torch.Tensor, res_samples, task: str, out_plan=None):
+        """out_plan = (crop_hw, out_hw, quantize): un-pad + bicubic resize back (+ 8-bit quantisation) in the layout kernel."""
         dec, lat = self.vae.decoder, self.vae.latent_channels
         if task not in dec.task_prompts:
             raise KeyError(task)
@@ -235,6 +238,8 @@ class SkipConnectedAutoEncoder(nn.Module):
             h = blk.run(h)
         h = dec.up_blocks[-1].run(h)
         h = ops.conv(dec.conv_norm_out.run(h, silu=True), dec.conv_out.packed(), out_f32=True)
+        if out_plan:
+            return ops.image_unpad_resize(h, dec.conv_out.out_channels, out_plan[0], out_plan[1], mul=0.5, add=0.5, quantize=out_plan[2])
         return ops.nhwc_to_nchw(h, c=dec.conv_out.out_channels, mul=0.5, add=0.5)             # (x+1)/2
 
     # ---- reference signatures ---------------------------------------------------------------------------------
@@ -323,11 +328,13 @@ class DiffUIE(nn.Module):
         return torch.cat(outs, 0), noise, torch.as_tensor(ts)
 
     # ---- the hot path ------------------------------------------------------------------------------------------------
-    def _forward_device(self, images, task, n_vae, n_t):
-        """images fp32 NCHW on device, padded to multiples of 64.  Returns (preds NCHW fp32, z0, zt) (NHWC fp32 latents)."""
+    def _forward_device(self, images, task, n_vae, n_t, plan, quantize=False):
+        """images fp32 NCHW on device (original size); plan = resize_pad_plan(H, W).
+        Returns (preds NCHW fp32 at the original size, z0, zt) (NHWC fp32 latents)."""
         lat = self.ae.vae.latent_channels
+        h, w, pad_h, pad_w = plan
         ops.arena(images.device).reset()             # zero the fused GroupNorm sums of the previous forward (one fill)
-        z0, z0b, mids = self.ae.encode_run(images, n_vae, enable_fr=self.fr_type is not None)
+        z0, z0b, mids = self.ae.encode_run(images, n_vae, enable_fr=self.fr_type is not None, plan=plan)
         zt = z0
         if self.control_type:
             ac = schedule.alphas_cumprod_f64()
@@ -342,54 +349,51 @@ class DiffUIE(nn.Module):
                 eps = self.base_model.run(ztb, control, i)
                 c_x, c_e = schedule.ddim_coefficients(int(t), self.num_inference_steps)
                 ops.ddim_step_(zt, ztb, eps, lat, c_x, c_e)
-        preds = self.ae.decode_run(zt, mids, task)
+        preds = self.ae.decode_run(zt, mids, task, out_plan=((h, w), tuple(images.shape[-2:]), quantize))
         return preds, z0, zt
 
     @torch.no_grad()
-    def forward(self, images, task: str, noise=None, return_latents=False):
-        """noise = (eps_vae, eps_t999): the two RNG draws of the reference (autoencoder.py:152, unifie.py:87), NCHW fp32."""
+    def forward(self, images, task: str, noise=None, return_latents=False, quantize=False):
+        """noise = (eps_vae, eps_t999): the two RNG draws of the reference (autoencoder.py:152, unifie.py:87), NCHW fp32.
+        quantize=True additionally applies the evaluator's mul(255).round().clamp(0,255).div(255) (eval_image_restoration.py:71).
+        Resize / reflect pad / un-pad / resize back (unifie.py:124-134,164-168) run as HIP kernels inside the graph."""
         if task not in self.ae.task_list and self.tedit:
             raise KeyError(task)
-        images = images.to(DEV).float()
+        images = images.to(DEV).float().contiguous()
         org_h, org_w = images.shape[-2:]
-        h, w, pad_h, pad_w = resize_pad_plan(org_h, org_w)
-        if (h, w) != (org_h, org_w):
-            images = F.interpolate(images, (h, w), mode="bicubic", align_corners=False, antialias=False)
-        if pad_h or pad_w:
-            images = F.pad(images, (0, pad_w, 0, pad_h), mode="reflect")
-        images = images.contiguous()
+        plan = resize_pad_plan(org_h, org_w)
+        h, w, pad_h, pad_w = plan
         b, lat = images.shape[0], self.ae.vae.latent_channels
-        lh, lw = images.shape[2] // 8, images.shape[3] // 8
+        lh, lw = (h + pad_h) // 8, (w + pad_w) // 8
         if noise is None:
             noise = (torch.randn(b, lat, lh, lw, device=DEV), torch.randn(b, lat, lh, lw, device=DEV))
         n_vae, n_t = (n.to(DEV).float().contiguous() for n in noise)
+        if tuple(n_vae.shape) != (b, lat, lh, lw) or tuple(n_t.shape) != (b, lat, lh, lw):
+            raise ValueError(f"noise must be two tensors of shape {(b, lat, lh, lw)}")
         self._prepare()
         if self.use_graph:
-            preds, z0, zt = self._graph_forward(images, task, n_vae, n_t)
+            preds, z0, zt = self._graph_forward(images, task, n_vae, n_t, plan, quantize)
         else:
-            preds, z0, zt = self._forward_device(images, task, n_vae, n_t)
-        preds = preds[..., :h, :w]
-        if (h, w) != (org_h, org_w):
-            preds = F.interpolate(preds, (org_h, org_w), mode="bicubic", align_corners=False, antialias=False)
+            preds, z0, zt = self._forward_device(images, task, n_vae, n_t, plan, quantize)
         if return_latents:
             return preds, ops.nhwc_to_nchw(z0, c=lat), ops.nhwc_to_nchw(zt, c=lat)
         return preds
 
     # ---- hipGraph: the whole fixed-length forward (encode, N denoise steps, decode) is one captured graph --------------
-    def _graph_forward(self, images, task, n_vae, n_t):
-        key = (tuple(images.shape), task)
+    def _graph_forward(self, images, task, n_vae, n_t, plan, quantize=False):
+        key = (tuple(images.shape), task, bool(quantize))
         g = self._graphs.get(key)
         if g is None:
             static = dict(images=images.clone(), n_vae=n_vae.clone(), n_t=n_t.clone())
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):                       # warm-up: packs weights, sizes workspaces, sets func attributes
-                self._forward_device(static["images"], task, static["n_vae"], static["n_t"])
+                self._forward_device(static["images"], task, static["n_vae"], static["n_t"], plan, quantize)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):    # an RCCL watchdog thread may be alive
-                outs = self._forward_device(static["images"], task, static["n_vae"], static["n_t"])
+                outs = self._forward_device(static["images"], task, static["n_vae"], static["n_t"], plan, quantize)
             g = self._graphs[key] = (graph, static, outs)
         graph, static, outs = g
         static["images"].copy_(images)

@@ -420,6 +420,25 @@ def nchw_to_nhwc(x: torch.Tensor, cpad=None, image=False):
     return out
 
 
+def image_resize_pad(img: torch.Tensor, rh: int, rw: int, ph: int, pw: int, mul=2.0, add=-1.0, cpad=None):
+    """DiffUIE.forward pre-processing (unifie.py:124-134) + x*2-1 + layout: fp32 NCHW -> bf16 NHWC [N, rh+ph, rw+pw, cpad]."""
+    img = img.contiguous().float()
+    n, c, h, w_ = img.shape
+    cpad = cpad or round_up(c, 8)
+    out = torch.empty((n, rh + ph, rw + pw, cpad), dtype=BF16, device=img.device)
+    check(lib.ur_image_resize_pad_nhwc(img.data_ptr(), out.data_ptr(), n, c, h, w_, rh, rw, ph, pw, cpad, mul, add, _stream()))
+    return out
+
+
+def image_unpad_resize(x: torch.Tensor, c: int, crop_hw, out_hw, mul=1.0, add=0.0, quantize=False):
+    """Post-processing (unifie.py:164-168 [+ eval_image_restoration.py:71 when quantize]): NHWC -> crop -> bicubic -> fp32 NCHW."""
+    n, xh, xw, ld = x.shape
+    out = torch.empty((n, c, out_hw[0], out_hw[1]), dtype=torch.float32, device=x.device)
+    check(lib.ur_image_unpad_resize_nchw(x.data_ptr(), int(x.dtype == torch.float32), out.data_ptr(), n, c, xh, xw, ld, crop_hw[0],
+                                         crop_hw[1], out_hw[0], out_hw[1], mul, add, int(quantize), _stream()))
+    return out
+
+
 def nhwc_to_nchw(x: torch.Tensor, c=None, mul=1.0, add=0.0):
     n, h, w_, ld = x.shape
     c = c or ld
