@@ -361,3 +361,24 @@ def test_image_unpad_resize_quantize(ops, f32, xh, xw, ch, cw, oh, ow):
     qref = ref.mul(255).round().clamp(0, 255).div(255)
     d = (q - qref).abs()
     assert d.max() <= 1.0 / 255 + 1e-6 and float((d > 1e-6).float().mean()) < 2e-3     # a rounding tie may flip one code value
+
+
+@pytest.mark.parametrize("n,c1,c2,cout,hw,img_bias", [(2, 1280, 0, 640, 16, False), (8, 256, 0, 128, 16, False), (3, 640, 320, 1280, 16, True),
+                                                      (4, 1280, 0, 1280, 8, False), (8, 640, 640, 256, 8, True), (4, 256, 0, 128, 8, False)])
+def test_conv_whole_image_halo_tiles(ops, n, c1, c2, cout, hw, img_bias):
+    """16x16 / 8x8 maps: whole-image halo tiles (one image / four images per tile), split over channel chunks, with the
+    virtual concat, residual, per-image bias rows and the GroupNorm sums coming out of the split-K reduce."""
+    g = _gen(n * cout + hw + c2)
+    cin = c1 + c2
+    x = _rb(torch.randn(n, cin, hw, hw, generator=g)); wt = _rb(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = torch.randn(cout, generator=g); r = _rb(torch.randn(n, cout, hw, hw, generator=g))
+    bi = torch.randn(n, cout, generator=g)
+    ops.arena().reset()
+    xa = _nhwc(x[:, :c1]); xb = _nhwc(x[:, c1:]) if c2 else None
+    pc = ops.pack_conv(wt, None if img_bias else b, "cuda")
+    y = ops.conv(xa, pc, x2=xb, residual=_nhwc(r), gn=True, bias=bi.cuda() if img_bias else None)
+    ref = F.conv2d(x, wt, None if img_bias else b, padding=1) + r + (bi[:, :, None, None] if img_bias else 0)
+    assert rel_l2(_nchw(y), ref) < TOL_BF16
+    st = ops.gn_of(y).view(n, cout, 2).cpu()
+    yf = _nchw(y).double()
+    assert rel_l2(st[..., 0], yf.sum((2, 3))) < 1e-5 and rel_l2(st[..., 1], (yf * yf).sum((2, 3))) < 1e-5

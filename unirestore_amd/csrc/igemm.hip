@@ -1233,6 +1233,196 @@ int launch_halo(ConvK& k, hipStream_t s) {
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
+// =====================================================================================================================
+// Whole-image halo tiles for the small feature maps (16 x 16: one image per tile; 8 x 8: four images per tile; BM = 256).
+// Same idea as igemm_halo_kernel - the input patch (with its zero border) is DMA'd into LDS once per 64-channel chunk and
+// the nine taps read shifted fragments from it - but here the tile is TH x TW x NIMG pixels of WHOLE images, so tile rows
+// are contiguous in M (plain epilogue / split-K paths apply), and the K loop is split over channel chunks (blockIdx.y)
+// because these layers have few tiles and K = 9 x 1280..2560.  A 32-pixel fragment spans several image rows; the slot
+// swizzle f(row) = ((row_in_image >> 1) - halo_y) & 7 keeps its ds_read_b128 conflict-free for both shapes
+// (searched with tools/lds_conflicts.py), at the price of a per-piece source chunk on the DMA side.
+template <int TH, int TW, int NIMG, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK p) {
+  constexpr int NW = WM * WN, BM = TH * TW * NIMG, PW = TW + 2, HP = (TH + 2) * PW, HPIX = HP * NIMG;
+  constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
+  constexpr int HPIECES = HSLOTS * NW, HBYTES = HPIECES * 1024;
+  constexpr int WBYTES = BN * 128, WPIECES = BN / 8, WPW = (WPIECES + NW - 1) / NW;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = NW * 64;
+  static_assert(BM == 256 && NW == 8 && WTM % 32 == 0 && WTN % 32 == 0 && HSLOTS <= 8, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const hbuf = smem;
+  unsigned char* const wring = smem + 2 * HBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid % WM, wn = wid / WM;
+  const int sz = blockIdx.y;
+  int id = blockIdx.x;
+  {
+    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = id % p.tiles_n, tmi = id / p.tiles_n;
+  const int n0 = tn * BN, img0 = tmi * NIMG, m0 = tmi * BM;
+
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const uint16_t* __restrict__ X1 = p.x;
+  const uint16_t* __restrict__ X2 = p.x2;
+  const uint16_t* __restrict__ Wt = p.w;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+  const int lr = lane >> 3, ps = lane & 7;
+
+  // halo pieces this wave issues per chunk: input pixel (or -1 = zero border) and the lane's logical 16-byte chunk
+  int hpix[HSLOTS], hchk[HSLOTS];
+#pragma unroll
+  for (int t = 0; t < HSLOTS; ++t) {
+    const int hr = (t * NW + wid) * 8 + lr;
+    const int im = hr / HP, rin = hr - im * HP, hy = rin / PW, hx = rin - hy * PW;
+    const int iy = hy - 1, ix = hx - 1;
+    const bool v = hr < HPIX && img0 + im < p.N && (unsigned)iy < (unsigned)TH && (unsigned)ix < (unsigned)TW;
+    hpix[t] = v ? ((img0 + im) * TH + iy) * TW + ix : -1;
+    hchk[t] = ps ^ (((rin >> 1) - hy) & 7);
+  }
+  const int wchunk = ps ^ ((((wid & 1) << 2) + (lr >> 1)) & 7);      // weight tile keeps the (row>>1)&7 swizzle
+  int woff[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
+    const int row = n0 + qq * 8 + lr;
+    woff[i] = row < p.Cout ? row * p.ldw : -1;
+  }
+  const int nchunk_all = p.nk / 9, cps = p.nk_per_split / 9;
+  const int c_begin = sz * cps, c_end = min(nchunk_all, c_begin + cps);
+  const int nchunk = c_end - c_begin, nk = nchunk * 9, kt0 = c_begin * 9;
+
+  auto issue_w = [&](int kt) {
+    unsigned char* st = wring + (kt % 3) * WBYTES;
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
+      const uint16_t* g = woff[i] >= 0 ? Wt + woff[i] + (kt0 + kt) * 64 + wchunk * 8 : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + qq * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_h = [&](int c, int t) {                                // c = chunk index local to this split
+    const int q = t * NW + wid;
+    int cc = (c_begin + c) * 64 + hchk[t] * 8;
+    const uint16_t* src = X1;
+    int ld = p.ldx;
+    if (cc >= p.C1) { src = X2; ld = p.ldx2; cc -= p.C1; }
+    const uint16_t* g = hpix[t] >= 0 ? src + hpix[t] * ld + cc : zero;
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(hbuf + (c & 1) * HBYTES + q * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  // this lane's pixel in each of the wave's FM fragments: halo row (tap 0,0) and halo y
+  int hrow0[FM], hin0[FM], hy0[FM];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int pix = wm * WTM + b * 32 + frow;
+    const int im = pix / (TH * TW), r = pix - im * (TH * TW), y = r / TW, x = r - y * TW;
+    hin0[b] = y * PW + x;
+    hrow0[b] = im * HP + hin0[b];
+    hy0[b] = y;
+  }
+
+#pragma unroll
+  for (int t = 0; t < HSLOTS; ++t) issue_h(0, t);
+  issue_w(0);
+  if (nk > 1) {
+    issue_w(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0, c = 0, tap = 0; kt < nk; ++kt) {
+    const bool more_w = kt + 2 < nk;
+    const bool more_h = tap < HSLOTS && c + 1 < nchunk;
+    if (more_w) issue_w(kt + 2);
+    if (more_h) {
+#pragma unroll
+      for (int t = 0; t < HSLOTS; ++t)
+        if (tap == t) issue_h(c + 1, t);
+    }
+    {
+      const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+      const unsigned char* hb = hbuf + (c & 1) * HBYTES;
+      const unsigned char* wsm = wring + (kt % 3) * WBYTES;
+      int hro[FM], hsw[FM];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        hro[b] = (hrow0[b] + dy * PW + dx) * 128;
+        hsw[b] = (((hin0[b] + dy * PW + dx) >> 1) - (hy0[b] + dy)) & 7;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int slot = ks * 2 + fhalf;
+        bf16x8 bfr[FM], afr[FN];
+#pragma unroll
+        for (int b = 0; b < FM; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hro[b] + ((slot ^ hsw[b]) << 4));
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+          const int row = wn * WTN + a * 32 + frow;
+          afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < FM; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
+    else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+    else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (++tap == 9) { tap = 0; ++c; }
+  }
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+}
+
+template <int TH, int TW, int NIMG, int BN, int WM, int WN>
+int launch_halo_img(ConvK& k, hipStream_t s) {
+  constexpr int NW = WM * WN, BM = TH * TW * NIMG, HPIX = (TH + 2) * (TW + 2) * NIMG, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
+  constexpr int HBYTES = HSLOTS * NW * 1024;
+  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = BM * (BN * 2 + 8) + 7 * BN * 4 + BM * 8;
+  constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  k.tiles_m = (k.N + NIMG - 1) / NIMG;
+  k.tiles_n = (k.Cout + BN - 1) / BN;
+  const int nchunk = k.nk / 9;
+  const long long tiles = (long long)k.tiles_m * k.tiles_n;
+  int splitk = 1;
+  if (tiles < 200 && k.ws) {      // one workgroup per CU: split the chunk range so that tiles * splits <= 256 (a single round)
+    splitk = (int)std::min<long long>(std::max<long long>(256 / tiles, 1), std::max(1, nchunk / 2));
+    while (splitk > 1 && (long long)splitk * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
+  }
+  const int cps = (nchunk + splitk - 1) / splitk;
+  k.splitk = (nchunk + cps - 1) / cps;
+  k.nk_per_split = cps * 9;
+  if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
+  k.gn_fused = k.gn_stats && k.splitk == 1 && (k.OHW % BM) == 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k);
+  if (k.splitk > 1) launch_splitk_reduce(k, s);
+  return ur::check_launch("ur_conv2d_nhwc");
+}
+
 int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   k.patch_tw = 0;
   static const bool no_halo = getenv("UR_IGEMM_NOHALO") != nullptr;
@@ -1254,6 +1444,16 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
     if (tiles8 >= 128 && (n160h || k.Cout % 128 == 0)) {
       if (n160h) return launch_halo<8, 160, 8, 1>(k, s);
       return launch_halo<8, 128, 4, 2>(k, s);
+    }
+  }
+  static const bool no_himg = getenv("UR_IGEMM_NOHIMG") != nullptr;
+  if (!no_himg && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && k.staged_ok_ && !pair && k.nbatch == 1 && !k.ups &&
+      k.OH == k.H && k.OW == k.W && !k.yt && k.Cout % 128 == 0 && k.nk >= 36) {
+    if (k.OH == 16 && k.OW == 16) return launch_halo_img<16, 16, 1, 128, 4, 2>(k, s);
+    if (k.OH == 8 && k.OW == 8 && k.N % 4 == 0) {
+      static const bool n64 = getenv("UR_IGEMM_HIMG64") != nullptr;
+      if (n64) return launch_halo_img<8, 8, 4, 64, 8, 1>(k, s);
+      return launch_halo_img<8, 8, 4, 128, 4, 2>(k, s);
     }
   }
   static const int sm_exp = getenv("UR_IGEMM_SM") ? atoi(getenv("UR_IGEMM_SM")) : 0;
