@@ -258,7 +258,8 @@ def test_conv_per_image_bias(ops):
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,k", [(2, 64, 128, 16, 16, 3), (8, 320, 320, 16, 16, 3), (2, 64, 64, 8, 8, 1), (1, 128, 256, 24, 8, 1),
-                                               (2, 1280, 640, 16, 16, 3), (3, 640, 1280, 8, 8, 3)])      # last two: split-K reduce leaves the sums
+                                               (2, 1280, 640, 16, 16, 3), (3, 640, 1280, 8, 8, 3),       # split-K reduce leaves the sums
+                                               (2, 320, 320, 32, 32, 3), (1, 640, 640, 32, 64, 3)])       # chunk-split 8x32 halo patches
 def test_conv_fused_groupnorm_stats(ops, n, cin, cout, h, w, k):
     """The conv epilogue (or its fallback pass) leaves per-image channel sums; GroupNorm consumes them without a stats pass."""
     g = _gen(cout + h)

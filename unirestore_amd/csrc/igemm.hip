@@ -209,7 +209,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
     for (int a = 0; a < FN; ++a)
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
-        int m = m0 + wm * WTM + b * 32 + mrow;
+        int m = tile_row_to_m(p, m0, wm * WTM + b * 32 + mrow);
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
@@ -1082,6 +1082,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid % WM, wn = wid / WM;
+  const int sz = blockIdx.y;
   int id = blockIdx.x;
   {
     const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
@@ -1122,20 +1123,22 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     const int row = n0 + qq * 8 + lr;
     woff[i] = row < p.Cout ? row * p.ldw : -1;
   }
-  const int nk = p.nk, nchunk = nk / 9;
+  // blockIdx.y splits the channel-chunk range (few-tile layers: tiles * splits <= one round of CUs)
+  const int cps = p.nk_per_split / 9, c_begin = sz * cps, nchunk = min(p.nk / 9, c_begin + cps) - c_begin;
+  const int nk = nchunk * 9, kt0 = c_begin * 9;
 
   auto issue_w = [&](int kt) {
     unsigned char* st = wring + (kt % 3) * WBYTES;
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
       const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
-      const uint16_t* g = woff[i] >= 0 ? Wt + woff[i] + kt * 64 + chunk * 8 : zero;
+      const uint16_t* g = woff[i] >= 0 ? Wt + woff[i] + (kt0 + kt) * 64 + chunk * 8 : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + qq * 1024), 16, 0, 0);
     }
   };
   auto issue_h = [&](int c, int t) {                                // halo piece (t*8 + wid) of chunk c
     const int q = t * NW + wid;
-    int cc = c * 64 + chunk * 8;
+    int cc = (c_begin + c) * 64 + chunk * 8;
     const uint16_t* src = X1;
     int ld = p.ldx;
     if (cc >= p.C1) { src = X2; ld = p.ldx2; cc -= p.C1; }
@@ -1207,7 +1210,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     __builtin_amdgcn_s_barrier();
     if (++tap == 9) { tap = 0; ++c; }
   }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, 0, 0, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 }
 
 template <int TH, int BN, int WM, int WN>
@@ -1218,18 +1221,31 @@ int launch_halo(ConvK& k, hipStream_t s) {
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   k.tiles_m = k.N * (k.OH / TH) * (k.OW / 32);
   k.tiles_n = (k.Cout + BN - 1) / BN;
-  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
-  k.splitk = 1;
-  k.nk_per_split = k.nk;
+  const int nchunk = k.nk / 9;
+  const long long tiles = (long long)k.tiles_m * k.tiles_n;
+  int splitk = 1;
+  static const bool no_hsplit = getenv("UR_IGEMM_NOHSPLIT") != nullptr;
+  if (!no_hsplit && tiles <= 128 && k.ws && !k.colsum) {     // <= half a round of CUs: split the chunk range, reduce in a second pass
+    splitk = (int)std::min<long long>(256 / tiles, std::max(1, nchunk / 2));
+    while (splitk > 1 && (long long)splitk * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
+  }
+  const int cps = (nchunk + splitk - 1) / splitk;
+  k.splitk = (nchunk + cps - 1) / cps;
+  k.nk_per_split = cps * 9;
+  if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
   k.patch_tw = 32;
-  k.gn_fused = k.gn_stats != nullptr;                      // a patch never leaves its image
+  k.gn_fused = k.gn_stats != nullptr && k.splitk == 1;     // a patch never leaves its image
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN>), dim3(k.tiles_m * k.tiles_n), dim3(NW * 64), lds, s, k);
+  hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k);
+  if (k.splitk > 1) {
+    k.patch_tw = 0;                                        // the partial planes are plain [M][Cout]
+    launch_splitk_reduce(k, s);
+  }
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
@@ -1428,21 +1444,22 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   static const bool no_halo = getenv("UR_IGEMM_NOHALO") != nullptr;
   if (!no_halo && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && k.staged_ok_ && !pair && k.nbatch == 1 &&
       k.OW % 32 == 0 && k.OH % 8 == 0 && k.OH == (k.ups ? 2 * k.H : k.H) && k.OW == (k.ups ? 2 * k.W : k.W) && !k.yt) {
-    const bool n160h = k.Cout % 160 == 0 && k.Cout % 128 != 0;
-    const bool n160e = k.Cout % 160 == 0;                      // 160-wide tiles also divide 640 / 1280 / ...
-    const long long tiles8 = (long long)k.N * (k.OH / 8) * (k.OW / 32) * ((k.Cout + (n160h ? 159 : 127)) / (n160h ? 160 : 128));
+    // tile width: 128 or 160 output channels, whichever divides Cout; when both do, the one whose tile count fills whole
+    // rounds of 256 CUs better (e.g. 1280 channels at 32 x 32: 8 x 160 -> 256 tiles = one round, 10 x 128 -> 320 = two)
+    const bool ok128 = k.Cout % 128 == 0, ok160 = k.Cout % 160 == 0;
+    const long long tm8 = (long long)k.N * (k.OH / 8) * (k.OW / 32);
+    // (<= 128 tiles are split over channel chunks into floor(256 / tiles) workgroups each)
+    auto eff = [](long long t) { return t <= 128 ? (double)(t * (256 / t)) / 256.0 : (double)t / (double)(((t + 255) / 256) * 256); };
+    static const bool old_w = getenv("UR_IGEMM_OLDW") != nullptr;
+    bool use160 = ok160 && (!ok128 || (!old_w && eff(tm8 * (k.Cout / 160)) >= eff(tm8 * (k.Cout / 128))));
+    const long long tiles8 = tm8 * (use160 ? k.Cout / 160 : k.Cout / 128);
     static const bool no_h4 = getenv("UR_IGEMM_H4") == nullptr;   // opt-in: measured slightly slower (weight ingest per flop doubles)
-    if (tiles8 >= 224 && (n160h || k.Cout % 128 == 0)) {
-      if (n160h) return launch_halo<8, 160, 8, 1>(k, s);
-      return launch_halo<8, 128, 4, 2>(k, s);
-    }
-    // mid-size maps (e.g. 8 x 32x32): 8x32 patches leave CUs idle; 4x32 patches x 160 channels give >= one tile per CU
-    if (!no_h4 && k.OH % 4 == 0 && n160e) {
+    if (!no_h4 && tiles8 < 224 && k.OH % 4 == 0 && ok160) {
       const long long tiles4 = (long long)k.N * (k.OH / 4) * (k.OW / 32) * (k.Cout / 160);
       if (tiles4 >= 192) return launch_halo<4, 160, 4, 1>(k, s);
     }
-    if (tiles8 >= 128 && (n160h || k.Cout % 128 == 0)) {
-      if (n160h) return launch_halo<8, 160, 8, 1>(k, s);
+    if ((ok128 || ok160) && tiles8 >= 64) {
+      if (use160) return launch_halo<8, 160, 8, 1>(k, s);
       return launch_halo<8, 128, 4, 2>(k, s);
     }
   }
