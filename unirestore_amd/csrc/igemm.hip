@@ -196,6 +196,92 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ConvK& p, f32x16 (&a
 // overwrites the residual tile in place with the result, and the tile leaves with 16-byte row-contiguous stores.
 // (The MFMA fragment layout would otherwise touch 16-byte runs per pixel per instruction, and a global bias load
 // inside each quad's branch serialised ~20 memory latencies per lane.)
+// Fragment pass of the staged epilogue: accumulators -> (LayerNorm transform) -> bias -> activation -> scale -> (+residual
+// from LDS) -> bf16 into the staged tile.  The feature flags are template parameters (0 = off, 1 = on, 2 = decided at run
+// time): the pass is unrolled FN x 4 x FM times, and with run-time flags every instance carries every feature - measured
+// 2.2 us of instruction-fetch stalls per launch on a cold CU.  The caller picks a lean specialisation once per tile.
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int SROW, int PAIR, int LN, int MULTI, int YT, int ACT>
+__device__ __forceinline__ void epi_frag_pass(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int c0, int wm, int wn, int lane,
+                                              int gb, unsigned char* smem, const float* sbias, const float* scol, const float* srow) {
+  const int fhalf = lane >> 5, mrow = lane & 31;
+  const bool pair_ = PAIR == 2 ? is_pair_act(p.act) : PAIR != 0;
+  const bool ln_ = LN == 2 ? p.ln_stats != nullptr : LN != 0;
+  const bool multi_ = MULTI == 2 ? (p.bias_img && !p.patch_tw && p.OHW < BM) : MULTI != 0;
+  const bool yt_ = YT == 2 ? p.yt != nullptr : YT != 0;
+  const bool act_ = ACT == 2 ? p.act != UR_ACT_NONE : ACT != 0;
+  const bool has_res = p.res != nullptr;
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    if (pair_ && (a & 1)) continue;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int ln = wn * WTN + a * 32 + rg * 8 + fhalf * 4;          // column inside the tile (GEMM-N space)
+      const int co_in = n0 + ln;
+      float4 bv = *reinterpret_cast<const float4*>(sbias + ln);
+      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pair_) gv = *reinterpret_cast<const float4*>(sbias + ln + 32);
+      const int lco = pair_ ? ((ln >> 6) * 32 + (ln & 31)) : ln;        // column inside the OUTPUT tile
+      const int co = c0 + lco;
+      const bool col_ok = co_in < p.Cout;
+      float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ln_) {
+        sv = *reinterpret_cast<const float4*>(scol + ln);
+        if (pair_) sg = *reinterpret_cast<const float4*>(scol + ln + 32);
+      }
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        const int lm = wm * WTM + b * 32 + mrow;
+        if (multi_) {                                  // tile spans several images: this row's own bias row
+          const int il = lm / p.OHW;
+          bv = *reinterpret_cast<const float4*>(sbias + il * BN + ln);
+          if (pair_) gv = *reinterpret_cast<const float4*>(sbias + il * BN + ln + 32);
+        }
+        float v[4], gq[4] = {0.f, 0.f, 0.f, 0.f};
+        constexpr int a1 = (FN > 1) ? 1 : 0;
+        if (ln_) {                                            // LayerNorm folded into this GEMM (see above)
+          const float mean = srow[2 * lm], rstd = srow[2 * lm + 1];
+          v[0] = rstd * (acc[a][b][rg * 4] - mean * sv.x) + bv.x;     v[1] = rstd * (acc[a][b][rg * 4 + 1] - mean * sv.y) + bv.y;
+          v[2] = rstd * (acc[a][b][rg * 4 + 2] - mean * sv.z) + bv.z; v[3] = rstd * (acc[a][b][rg * 4 + 3] - mean * sv.w) + bv.w;
+          if (pair_) {
+            gq[0] = rstd * (acc[(a + a1) % FN][b][rg * 4] - mean * sg.x) + gv.x;     gq[1] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 1] - mean * sg.y) + gv.y;
+            gq[2] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 2] - mean * sg.z) + gv.z; gq[3] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 3] - mean * sg.w) + gv.w;
+          }
+        } else {
+          v[0] = acc[a][b][rg * 4] + bv.x; v[1] = acc[a][b][rg * 4 + 1] + bv.y;
+          v[2] = acc[a][b][rg * 4 + 2] + bv.z; v[3] = acc[a][b][rg * 4 + 3] + bv.w;
+          if (pair_) {
+            gq[0] = acc[(a + a1) % FN][b][rg * 4] + gv.x; gq[1] = acc[(a + a1) % FN][b][rg * 4 + 1] + gv.y;
+            gq[2] = acc[(a + a1) % FN][b][rg * 4 + 2] + gv.z; gq[3] = acc[(a + a1) % FN][b][rg * 4 + 3] + gv.w;
+          }
+        }
+        if (pair_) {
+          const float g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3];
+          if (p.act == UR_ACT_GEGLU) { v[0] *= gelu_f(g0); v[1] *= gelu_f(g1); v[2] *= gelu_f(g2); v[3] *= gelu_f(g3); }
+          else { v[0] *= g0; v[1] *= g1; v[2] *= g2; v[3] *= g3; }
+        } else if (act_) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+        const int mg = tile_row_to_m(p, m0, lm);
+        const bool ok = col_ok && mg < p.M;
+        if (yt_ && co >= p.n_split) {                                   // transposed columns (V^T) go out directly
+          if (ok) epi_store(p, gb, mg, co, v);
+          continue;
+        }
+        uint2* sp = reinterpret_cast<uint2*>(smem + lm * SROW + lco * 2);
+        if (has_res) {
+          const uint2 rv = *sp;
+          v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+          v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+        }
+        if (ok) *sp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+    }
+  }
+}
+
 template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT>
 __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
                                                int gb, int sz, unsigned char* smem, bool owner = true) {
@@ -266,77 +352,16 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
     else tile_copy<BM, BN, NT, SROW, true>(p, rb, p.ldr, smem, m0, p.M, c0, cmax);
   }
   __syncthreads();
-  const bool has_res = p.res != nullptr;
-  if (owner)
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    if (pair && (a & 1)) continue;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int ln = wn * WTN + a * 32 + rg * 8 + fhalf * 4;          // column inside the tile (GEMM-N space)
-      const int co_in = n0 + ln;
-      float4 bv = *reinterpret_cast<const float4*>(sbias + ln);
-      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pair) gv = *reinterpret_cast<const float4*>(sbias + ln + 32);
-      const int lco = pair ? ((ln >> 6) * 32 + (ln & 31)) : ln;        // column inside the OUTPUT tile
-      const int co = c0 + lco;
-      const bool col_ok = co_in < p.Cout;
-      float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sg = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.ln_stats) {
-        sv = *reinterpret_cast<const float4*>(scol + ln);
-        if (pair) sg = *reinterpret_cast<const float4*>(scol + ln + 32);
-      }
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        const int lm = wm * WTM + b * 32 + mrow;
-        if (nimg_tile > 1) {                                  // tile spans several images: this row's own bias row
-          const int il = lm / p.OHW;
-          bv = *reinterpret_cast<const float4*>(sbias + il * BN + ln);
-          if (pair) gv = *reinterpret_cast<const float4*>(sbias + il * BN + ln + 32);
-        }
-        float v[4], gq[4] = {0.f, 0.f, 0.f, 0.f};
-        constexpr int a1 = (FN > 1) ? 1 : 0;
-        if (p.ln_stats) {                                     // LayerNorm folded into this GEMM (see above)
-          const float mean = srow[2 * lm], rstd = srow[2 * lm + 1];
-          v[0] = rstd * (acc[a][b][rg * 4] - mean * sv.x) + bv.x;     v[1] = rstd * (acc[a][b][rg * 4 + 1] - mean * sv.y) + bv.y;
-          v[2] = rstd * (acc[a][b][rg * 4 + 2] - mean * sv.z) + bv.z; v[3] = rstd * (acc[a][b][rg * 4 + 3] - mean * sv.w) + bv.w;
-          if (pair) {
-            gq[0] = rstd * (acc[(a + a1) % FN][b][rg * 4] - mean * sg.x) + gv.x;     gq[1] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 1] - mean * sg.y) + gv.y;
-            gq[2] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 2] - mean * sg.z) + gv.z; gq[3] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 3] - mean * sg.w) + gv.w;
-          }
-        } else {
-          v[0] = acc[a][b][rg * 4] + bv.x; v[1] = acc[a][b][rg * 4 + 1] + bv.y;
-          v[2] = acc[a][b][rg * 4 + 2] + bv.z; v[3] = acc[a][b][rg * 4 + 3] + bv.w;
-          if (pair) {
-            gq[0] = acc[(a + a1) % FN][b][rg * 4] + gv.x; gq[1] = acc[(a + a1) % FN][b][rg * 4 + 1] + gv.y;
-            gq[2] = acc[(a + a1) % FN][b][rg * 4 + 2] + gv.z; gq[3] = acc[(a + a1) % FN][b][rg * 4 + 3] + gv.w;
-          }
-        }
-        if (pair) {
-          const float g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3];
-          if (p.act == UR_ACT_GEGLU) { v[0] *= gelu_f(g0); v[1] *= gelu_f(g1); v[2] *= gelu_f(g2); v[3] *= gelu_f(g3); }
-          else { v[0] *= g0; v[1] *= g1; v[2] *= g2; v[3] *= g3; }
-        } else if (p.act != UR_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-        const int mg = tile_row_to_m(p, m0, lm);
-        const bool ok = col_ok && mg < p.M;
-        if (p.yt && co >= p.n_split) {                                   // transposed columns (V^T) go out directly
-          if (ok) epi_store(p, gb, mg, co, v);
-          continue;
-        }
-        uint2* sp = reinterpret_cast<uint2*>(smem + lm * SROW + lco * 2);
-        if (has_res) {
-          const uint2 rv = *sp;
-          v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-          v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-        }
-        if (ok) *sp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-      }
-    }
+  if (owner) {
+    // lean specialisations for the common launches; everything else takes the all-run-time instance
+    const bool multi = nimg_tile > 1, hasact = p.act != UR_ACT_NONE;
+#define UR_EPI_PASS(PAIR, LN, MULTI, YT, ACT) \
+    epi_frag_pass<FM, FN, WTM, WTN, BM, BN, SROW, PAIR, LN, MULTI, YT, ACT>(p, acc, m0, n0, c0, wm, wn, lane, gb, smem, sbias, scol, srow)
+    if (!pair && !p.ln_stats && !multi && !p.yt) { if (hasact) UR_EPI_PASS(0, 0, 0, 0, 1); else UR_EPI_PASS(0, 0, 0, 0, 0); }
+    else if (!pair && p.ln_stats && !multi && !p.yt && !hasact) UR_EPI_PASS(0, 1, 0, 0, 0);
+    else if (pair && !multi && !p.yt) { if (p.ln_stats) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0); }
+    else UR_EPI_PASS(2, 2, 2, 2, 2);
+#undef UR_EPI_PASS
   }
   if (p.dbg & 16) return;
   __syncthreads();

@@ -1,5 +1,9 @@
 // HBM-bound normalisation kernels for gfx950: GroupNorm(+SiLU) / InstanceNorm over NHWC bf16,
 // LayerNorm over the channel dim, row softmax.  16-byte vector accesses, fp32 math, fp64 global stats.
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
 #include "common.h"
 
 namespace {
@@ -319,7 +323,15 @@ int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma
   UR_REQUIRE((size_t)C * 8 <= 64 * 1024, "C too large");
   hipStream_t s = (hipStream_t)stream;
   const double bytes = 2.0 * N * HW * (double)C;
-  ur::ProfScope prof("groupnorm", 0.0, 3.0 * bytes, s);
+  const char* fam = "groupnorm";
+  static const bool prof_shapes = getenv("UR_PROF_SHAPES") != nullptr;
+  if (prof_shapes) {                                     // per-shape families for tools/prof_shapes.py
+    static std::map<std::string, int> interned;
+    char buf[96];
+    snprintf(buf, sizeof buf, "gn N%d HW%d C%d+%d pre%d", N, HW, C1, x2 ? C2 : 0, (pre1 ? 1 : 0) + (x2 && pre2 ? 1 : 0));
+    fam = interned.emplace(buf, 0).first->first.c_str();
+  }
+  ur::ProfScope prof(fam, 0.0, 3.0 * bytes, s);
   // ws = [N][C][2] fp64 sums, ZERO AT REST (the caller zero-fills once, the finalize kernel re-zeroes what it read);
   // ab = [N][2][C] fp32 affine table (plain scratch; separate so it can never alias another call's sums)
   double* stats = (double*)ws;
