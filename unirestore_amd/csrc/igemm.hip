@@ -282,43 +282,20 @@ __device__ __forceinline__ void epi_frag_pass(const ConvK& p, f32x16 (&acc)[FN][
   }
 }
 
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT>
-__device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
-                                               int gb, int sz, unsigned char* smem, bool owner = true) {
-  // owner: this wave holds accumulator fragments (false for the loader waves of the warp-specialised kernel,
-  // which still take part in the barriers and the tile copies)
-  const int fhalf = lane >> 5, mrow = lane & 31;
-  if (p.splitk > 1) {
-    if (!owner) return;
-    float* ws = p.ws + ((long long)(sz * p.nbatch + gb) * p.M) * p.Cout;
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        int m = tile_row_to_m(p, m0, wm * WTM + b * 32 + mrow);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
-          if (m < p.M && co < p.Cout)
-            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =
-                make_float4(acc[a][b][rg * 4], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
-        }
-      }
-    return;
-  }
-  const bool pair = is_pair_act(p.act);
-  constexpr int SROW = BN * 2 + 8;                       // staged row stride in bytes (+8 spreads the ds_write_b64 banks)
-  // per-image bias rows (time embeddings of a schedule-batched Controller): a tile covers 1 image, or up to 4 whole ones
-  const int nimg_tile = (p.bias_img && !p.patch_tw && p.OHW < BM) ? BM / p.OHW : 1;
-  const bool bias_geom_ok = !p.bias_img || p.patch_tw || (p.OHW % BM) == 0 || ((BM % p.OHW) == 0 && nimg_tile <= 4);
-  const bool staged = p.staged_ok_ && BN >= 32 && bias_geom_ok;   // host-evaluated part: bf16 y, 16-byte aligned rows, no colsum
-  if (!staged) {
-    if (owner) igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
-    return;
-  }
+// Staged epilogue body.  CLS 0 = the plain class (no pair activation, no LayerNorm consumer, one bias row per tile, no
+// transposed columns): those features are compiled out, so the executed path is short and contiguous (skipping over
+// feature blocks costs an instruction-cache miss per far branch on a cold CU).  CLS 1 = everything, decided at run time.
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, int CLS>
+__device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
+                                                int gb, unsigned char* smem, bool owner, int nimg_tile_in) {
+  constexpr int SROW = BN * 2 + 8;
+  const bool pair = CLS ? is_pair_act(p.act) : false;
+  const bool ln = CLS ? p.ln_stats != nullptr : false;
+  const bool yt = CLS ? p.yt != nullptr : false;
+  const int nimg_tile = CLS ? nimg_tile_in : 1;
   const int c0 = pair ? (n0 >> 1) : n0;                  // first output column of this tile
   const int ncols = pair ? BN / 2 : BN;
-  const int cmax = min(p.yt ? p.n_split : (pair ? p.Cout / 2 : p.Cout), c0 + ncols) - c0;     // valid output columns here
+  const int cmax = min(yt ? p.n_split : (pair ? p.Cout / 2 : p.Cout), c0 + ncols) - c0;     // valid output columns here
   float* sbias = reinterpret_cast<float*>(smem + BM * SROW);                                   // [nimg_tile][BN] floats (GEMM-N order)
   float* facc = sbias + 4 * BN;                                                                // [2][BN] fused GroupNorm sums
   float* scol = facc + 2 * BN;                                                                 // [BN] LN fusion: column sums of W*gamma
@@ -331,7 +308,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   }
   if (p.gn_fused)
     for (int i = threadIdx.x; i < 2 * BN; i += NT) facc[i] = 0.f;
-  if (p.ln_stats) {   // this GEMM consumes LayerNorm(x): out = rstd*(acc - mean*s[n]) + t[n]  (t arrives as the bias)
+  if (ln) {   // this GEMM consumes LayerNorm(x): out = rstd*(acc - mean*s[n]) + t[n]  (t arrives as the bias)
     for (int i = threadIdx.x; i < BN; i += NT) scol[i] = n0 + i < p.Cout ? p.ln_colsum[n0 + i] : 0.f;
     for (int r = threadIdx.x; r < BM; r += NT) {
       const int m = min(tile_row_to_m(p, m0, r), p.M - 1);
@@ -357,9 +334,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
     const bool multi = nimg_tile > 1, hasact = p.act != UR_ACT_NONE;
 #define UR_EPI_PASS(PAIR, LN, MULTI, YT, ACT) \
     epi_frag_pass<FM, FN, WTM, WTN, BM, BN, SROW, PAIR, LN, MULTI, YT, ACT>(p, acc, m0, n0, c0, wm, wn, lane, gb, smem, sbias, scol, srow)
-    if (!pair && !p.ln_stats && !multi && !p.yt) { if (hasact) UR_EPI_PASS(0, 0, 0, 0, 1); else UR_EPI_PASS(0, 0, 0, 0, 0); }
-    else if (!pair && p.ln_stats && !multi && !p.yt && !hasact) UR_EPI_PASS(0, 1, 0, 0, 0);
-    else if (pair && !multi && !p.yt) { if (p.ln_stats) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0); }
+    if (CLS == 0) { if (hasact) UR_EPI_PASS(0, 0, 0, 0, 1); else UR_EPI_PASS(0, 0, 0, 0, 0); }
+    else if (!pair && ln && !multi && !yt && !hasact) UR_EPI_PASS(0, 1, 0, 0, 0);
+    else if (pair && !multi && !yt) { if (ln) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0); }
     else UR_EPI_PASS(2, 2, 2, 2, 2);
 #undef UR_EPI_PASS
   }
@@ -417,8 +394,48 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   else tile_copy<BM, BN, NT, SROW, false>(p, yb, p.ldy, smem, m0, p.M, c0, cmax);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT>
+__device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
+                                               int gb, int sz, unsigned char* smem, bool owner = true) {
+  // owner: this wave holds accumulator fragments (false for the loader waves of the warp-specialised kernel,
+  // which still take part in the barriers and the tile copies)
+  const int fhalf = lane >> 5, mrow = lane & 31;
+  if (p.splitk > 1) {
+    if (!owner) return;
+    float* ws = p.ws + ((long long)(sz * p.nbatch + gb) * p.M) * p.Cout;
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        int m = tile_row_to_m(p, m0, wm * WTM + b * 32 + mrow);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
+          if (m < p.M && co < p.Cout)
+            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =
+                make_float4(acc[a][b][rg * 4], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
+        }
+      }
+    return;
+  }
+  const bool pair = is_pair_act(p.act);
+  constexpr int SROW = BN * 2 + 8;                       // staged row stride in bytes (+8 spreads the ds_write_b64 banks)
+  // per-image bias rows (time embeddings of a schedule-batched Controller): a tile covers 1 image, or up to 4 whole ones
+  const int nimg_tile = (p.bias_img && !p.patch_tw && p.OHW < BM) ? BM / p.OHW : 1;
+  const bool bias_geom_ok = !p.bias_img || p.patch_tw || (p.OHW % BM) == 0 || ((BM % p.OHW) == 0 && nimg_tile <= 4);
+  const bool staged = p.staged_ok_ && BN >= 32 && bias_geom_ok;   // host-evaluated part: bf16 y, 16-byte aligned rows, no colsum
+  if (!staged) {
+    if (owner) igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
+    return;
+  }
+  const bool plain = !pair && !p.ln_stats && nimg_tile == 1 && !p.yt;
+  if (plain) staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 0>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
+  else staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 1>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
+}
+
+template <int BM, int BN, int WM, int WN, bool G1 = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
+  // G1: pure GEMM (1x1, stride 1, one source, no padding): rows are plain offsets, no im2col state, no tap bookkeeping
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, XP = BM / 32, WP = BN / 32;
   constexpr int STAGE = (BM + BN) * 128;
   static_assert(WM * WN == 4 && WTM % 32 == 0 && WTN % 32 == 0, "tile/wave shape");
@@ -449,6 +466,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
   for (int i = 0; i < XP; ++i) {
     int m = m0 + i * 32 + lrow;
     xok[i] = m < p.M;
+    if (G1) { nb[i] = xok[i] ? m * p.ldx : 0; ih0[i] = iw0[i] = 0; continue; }    // nb = element offset of the row
     int mm = xok[i] ? m : 0;
     int n = mm / p.OHW, rem = mm - n * p.OHW;
     int oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -469,13 +487,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
   const int kt_begin = sz * p.nk_per_split;
   const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
   int kcur = kt_begin * 64 + chunk * 8;
-  int tap = kcur / p.Cin, cch = kcur - tap * p.Cin;
+  int tap = 0, cch = kcur;
   const int ntap = p.KH * p.KW;
-  if (p.kcm) { tap = kt_begin % ntap; cch = (kt_begin / ntap) * 64 + chunk * 8; }
+  if (!G1) {
+    tap = kcur / p.Cin; cch = kcur - tap * p.Cin;
+    if (p.kcm) { tap = kt_begin % ntap; cch = (kt_begin / ntap) * 64 + chunk * 8; }
+  }
 
   uint4 xr[XP], wr[WP];
   auto load_tile = [&]() {
     const bool kval = kcur < p.Ktot;
+    if (G1) {
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const bool v = kval && xok[i];
+        const uint4 val = *reinterpret_cast<const uint4*>(v ? X1 + nb[i] + kcur : X1);
+        xr[i] = v ? val : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < WP; ++j) {
+        const bool v = kval && wok[j];
+        const uint4 val = *reinterpret_cast<const uint4*>(v ? Wt + woff[j] + kcur : Wt);
+        wr[j] = v ? val : make_uint4(0, 0, 0, 0);
+      }
+      kcur += 64;
+      return;
+    }
     const int dy = (p.KW == 1) ? 0 : (tap * 11) >> 5;
     const int dx = tap - dy * p.KW;
     const uint16_t* src = X1;
@@ -757,12 +794,18 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, k);
+  static const bool no_g1 = getenv("UR_IGEMM_NOG1") != nullptr;
+  const bool g1 = !no_g1 && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.pad_t == 0 && k.pad_l == 0 && k.OH == k.H && k.OW == k.W &&
+                  (long long)k.M * k.ldx + k.Ktot < (1ll << 31);
+  if (g1) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), lds, s, k);
+  else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), lds, s, k);
   if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
 }
