@@ -23,3 +23,12 @@ def gn():
 print("GN tiny (stats+finalize+apply + arena fill) us:", round(gtime(gn, reps=100), 2))
 q = torch.randn(1, 64, 192, device="cuda").to(torch.bfloat16); vt = torch.randn(1, 64, 64, device="cuda").to(torch.bfloat16)
 print("attention tiny            us/launch:", round(gtime(lambda: ops.attention(q, q[:, :, 64:], vt, 1, 64, 64, 64, 0.125, ldq=192, ldk=192, bs_q=64*192, bs_k=64*192, bs_vt=64*64, batch=1), reps=200), 2))
+for kk in (64, 320, 640, 1280, 2560):
+    xk = torch.randn(1, 8, 8, kk, device="cuda").to(torch.bfloat16)
+    pk = ops.pack_conv(torch.randn(64, kk, 1, 1) / kk ** 0.5, torch.randn(64), "cuda")
+    print(f"1x1 tiny K={kk:5d} ({kk // 64:2d} k-tiles)  us/launch:", round(gtime(lambda: ops.conv(xk, pk, out=y), reps=200), 2))
+for kk in (640, 1280):
+    xk = torch.randn(2048, kk, device="cuda").to(torch.bfloat16)
+    pk = ops.pack_conv(torch.randn(1280, kk, 1, 1) / kk ** 0.5, torch.randn(1280), "cuda")
+    yk = torch.empty(2048, 1280, device="cuda", dtype=torch.bfloat16)
+    print(f"M2048 N1280 K={kk} us/launch:", round(gtime(lambda: ops.linear(xk, pk), reps=50), 2))

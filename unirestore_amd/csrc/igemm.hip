@@ -12,1500 +12,26 @@
 //     ds_write_b128 staging pattern and the ds_read_b128 fragment pattern of 32-row MFMA operands.
 //   * zero padding, stride, nearest-2x upsample and channel concat are address arithmetic in the loader.
 //   * block id -> tile map is XCD-aware (blocks that share an activation tile land on one XCD's L2).
-#include <cstdio>
-#include <cstdlib>
-#include <map>
-#include <string>
+#include "igemm_impl.h"
 
-#include "common.h"
-
-// 128 B of zeros: the global source of every padded / out-of-range 16-byte piece of the LDS-DMA loader.
-__device__ uint4 g_zero_page[8];
+namespace urk {   // launcher instantiations live in igemm_v1a/v1b/v2/halo.hip (parallel compilation)
+int v1_128x128(void* kp, hipStream_t s);
+int v1_128x160(void* kp, hipStream_t s);
+int v1_128x64(void* kp, hipStream_t s);
+int v1_256x32(void* kp, hipStream_t s);
+int v1_64x64(void* kp, hipStream_t s);
+int v2_256x32(void* kp, hipStream_t s);
+int v2_128x64(void* kp, hipStream_t s);
+int v2_256x160(void* kp, hipStream_t s);
+int v2_256x128(void* kp, hipStream_t s);
+int gemm_256x256(void* kp, hipStream_t s);
+int halo_8x32_160(void* kp, hipStream_t s);
+int halo_8x32_128(void* kp, hipStream_t s);
+int himg_16x16(void* kp, hipStream_t s);
+int himg_8x8x4(void* kp, hipStream_t s);
+}  // namespace urk
 
 namespace {
-
-struct ConvK {
-  const uint16_t* x; const uint16_t* x2; const uint16_t* w; const float* bias; const uint16_t* res;
-  void* y; uint16_t* yt; float* colsum; float* ws; double* gn_stats;
-  float* row_stats; const float* ln_stats; const float* ln_colsum; float ln_eps; int ln_dim, ln_parts;
-  int dry, plan_tn;
-  int N, H, W, C1, ldx, C2, ldx2, Cin, Cout, ldw, ldy, ldr, KH, KW, stride, pad_t, pad_l, OH, OW, OHW;
-  int ups, act, out_f32, n_split, t_rows, t_ld;
-  float out_scale, colsum_scale;
-  int M, Ktot, nk, tiles_m, tiles_n, splitk, nk_per_split, nbatch;
-  long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r, bias_img;
-  size_t ws_bytes_;
-  int dbg, gn_fused, staged_ok_;
-  int patch_tw, patch_m0_unused;   // >0: tile rows are an (BM/patch_tw) x patch_tw pixel patch of one image (halo kernel)
-  int kcm;   // 1: K runs (64-channel chunk, tap, channel) - the 9 taps of a chunk are consecutive K tiles (L2 reuse)
-};
-
-__device__ __forceinline__ bool is_pair_act(int act) { return act == UR_ACT_GEGLU || act == UR_ACT_GATE; }
-
-// tile row r -> global output row.  Linear tiles: m0 + r.  Patch tiles (halo kernel): m0 is the patch's first pixel and
-// rows run (py, px) over a patch_tw-wide window of an OW-wide image.
-__device__ __forceinline__ int tile_row_to_m(const ConvK& p, int m0, int r) {
-  return p.patch_tw ? m0 + (r / p.patch_tw) * p.OW + (r % p.patch_tw) : m0 + r;
-}
-
-// Final stage for 4 consecutive output channels [co, co+4) of pixel row m (values already activated/scaled).
-__device__ __forceinline__ void epi_residual(const ConvK& p, int gb, int m, int co, float v[4]) {
-  if (p.res) {
-    const uint16_t* r = p.res + gb * p.bs_r + (long long)m * p.ldr + co;
-    uint2 rv = *reinterpret_cast<const uint2*>(r);
-    v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-    v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-  }
-}
-
-__device__ __forceinline__ void epi_store(const ConvK& p, int gb, int m, int co, float v[4]) {
-  if (p.res) {
-    const uint16_t* r = p.res + gb * p.bs_r + (long long)m * p.ldr + co;
-    uint2 rv = *reinterpret_cast<const uint2*>(r);
-    v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-    v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-  }
-  if (p.yt && co >= p.n_split) {
-    int b = m / p.t_rows, t = m - b * p.t_rows;
-    int cw = p.Cout - p.n_split;
-    uint16_t* o = p.yt + ((long long)b * cw + (co - p.n_split)) * p.t_ld + t;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[(long long)e * p.t_ld] = f2bf(v[e]);
-    return;
-  }
-  if (!p.y) return;
-  if (p.out_f32) {
-    float* o = reinterpret_cast<float*>(p.y) + gb * p.bs_y + (long long)m * p.ldy + co;
-    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-  } else {
-    uint16_t* o = reinterpret_cast<uint16_t*>(p.y) + gb * p.bs_y + (long long)m * p.ldy + co;
-    *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-  }
-}
-
-// bias + activation + scale on a quad; `g` is the gate quad for pair activations. co_in = column in the
-// GEMM's N space (pre-pairing); returns the output column.
-__device__ __forceinline__ int epi_act(const ConvK& p, int gb, int m, int co_in, float a[4], const float g[4]) {
-  const long long boff = gb * p.bs_bias + (p.bias_img ? (long long)(m / p.OHW) * p.bias_img : 0);
-  if (p.bias) {
-    const float* b = p.bias + boff + co_in;
-    float4 bv = *reinterpret_cast<const float4*>(b);
-    a[0] += bv.x; a[1] += bv.y; a[2] += bv.z; a[3] += bv.w;
-  }
-  int co = co_in;
-  if (is_pair_act(p.act)) {
-    float gg[4] = {g[0], g[1], g[2], g[3]};
-    if (p.bias) {
-      float4 bv = *reinterpret_cast<const float4*>(p.bias + boff + co_in + 32);
-      gg[0] += bv.x; gg[1] += bv.y; gg[2] += bv.z; gg[3] += bv.w;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] *= (p.act == UR_ACT_GEGLU) ? gelu_f(gg[e]) : gg[e];
-    co = (co_in >> 6) * 32 + (co_in & 31);
-  } else if (p.act != UR_ACT_NONE) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] = apply_act(a[e], p.act);
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) a[e] *= p.out_scale;
-  return co;
-}
-
-// Shared epilogue: acc[FN][FM] 32x32 fragments of the wave tile at (m0 + wm*WTM, n0 + wn*WTN).
-// Row-contiguous tile <-> global copy with 16-byte accesses; NC (tile columns) is a compile-time constant so the
-// (row, chunk) split is a multiply-shift, and LDS rows (stride SROW, 8-byte aligned) are touched with ds_*_b64.
-// Loads are issued in batches of U before any is consumed (latency paid once per batch, not once per chunk).
-template <int BM, int NC, int NT, int SROW, bool LOAD>
-__device__ __forceinline__ void tile_copy(const ConvK& p, uint16_t* g, long long ld, unsigned char* smem, int m0, int M, int c0,
-                                          int cmax) {
-  constexpr int Q = NC / 8;                               // 16-byte chunks per row
-  constexpr int TOT = BM * Q, U = 5;
-  for (int i0 = threadIdx.x; i0 < TOT; i0 += NT * U) {
-    uint4 v[U];
-    uint16_t* gp[U];
-    uint2* lp[U];
-    bool ok[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * NT;
-      const int r = i / Q, c = (i - r * Q) * 8;
-      const int m = tile_row_to_m(p, m0, i < TOT ? r : 0);
-      ok[u] = i < TOT && m < M && c < cmax;
-      gp[u] = g + (long long)(ok[u] ? m : m0) * ld + c0 + (ok[u] ? c : 0);
-      lp[u] = reinterpret_cast<uint2*>(smem + (ok[u] ? r * SROW + c * 2 : 0));
-      if (LOAD) v[u] = *reinterpret_cast<const uint4*>(gp[u]);
-      else { const uint2 a = lp[u][0], b = lp[u][1]; v[u] = make_uint4(a.x, a.y, b.x, b.y); }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!ok[u]) continue;
-      if (LOAD) { lp[u][0] = make_uint2(v[u].x, v[u].y); lp[u][1] = make_uint2(v[u].z, v[u].w); }
-      else *reinterpret_cast<uint4*>(gp[u]) = v[u];
-    }
-  }
-}
-
-// Generic (unstaged) epilogue: fp32 outputs, transposed outputs, fused column sums, odd leading dimensions.
-template <int FM, int FN, int WTM, int WTN>
-__device__ __forceinline__ void igemm_epilogue_direct(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn,
-                                                      int lane, int gb) {
-  const int fhalf = lane >> 5, mrow = lane & 31;
-  const bool pair = is_pair_act(p.act);
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    if (pair && (a & 1)) continue;
-#pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      int m = m0 + wm * WTM + b * 32 + mrow;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        int co_in = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
-        bool ok = m < p.M && co_in < p.Cout;
-        float v[4], g[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][rg * 4 + e];
-        if (pair) {
-          constexpr int a1 = (FN > 1) ? 1 : 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = acc[(a + a1) % FN][b][rg * 4 + e];
-        }
-        int co = co_in;
-        if (ok) co = epi_act(p, gb, m, co_in, v, g);
-        if (p.colsum) {  // per-image column sums of the activated output (all 32 lanes share co)
-          int mclamp = min(m, p.M - 1);
-          int img = mclamp / p.OHW;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float s = ok ? v[e] : 0.f;
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-            s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
-            if (mrow == 0 && co_in < p.Cout) {
-              int cw = pair ? p.Cout / 2 : p.Cout;   // colsum is [N][nbatch*cw]: batch index = channel group
-              atomicAdd(p.colsum + ((long long)img * p.nbatch + gb) * cw + co + e, s * p.colsum_scale);
-            }
-          }
-        }
-        if (ok) epi_store(p, gb, m, co, v);
-      }
-    }
-  }
-}
-
-// Shared epilogue.  The common case (bf16 output) is STAGED: bias row and residual tile are brought into LDS with
-// coalesced 16-byte loads (the K ring is free by then), the fragment pass is branch-free LDS-only math that
-// overwrites the residual tile in place with the result, and the tile leaves with 16-byte row-contiguous stores.
-// (The MFMA fragment layout would otherwise touch 16-byte runs per pixel per instruction, and a global bias load
-// inside each quad's branch serialised ~20 memory latencies per lane.)
-// Fragment pass of the staged epilogue: accumulators -> (LayerNorm transform) -> bias -> activation -> scale -> (+residual
-// from LDS) -> bf16 into the staged tile.  The feature flags are template parameters (0 = off, 1 = on, 2 = decided at run
-// time): the pass is unrolled FN x 4 x FM times, and with run-time flags every instance carries every feature - measured
-// 2.2 us of instruction-fetch stalls per launch on a cold CU.  The caller picks a lean specialisation once per tile.
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int SROW, int PAIR, int LN, int MULTI, int YT, int ACT>
-__device__ __forceinline__ void epi_frag_pass(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int c0, int wm, int wn, int lane,
-                                              int gb, unsigned char* smem, const float* sbias, const float* scol, const float* srow) {
-  const int fhalf = lane >> 5, mrow = lane & 31;
-  const bool pair_ = PAIR == 2 ? is_pair_act(p.act) : PAIR != 0;
-  const bool ln_ = LN == 2 ? p.ln_stats != nullptr : LN != 0;
-  const bool multi_ = MULTI == 2 ? (p.bias_img && !p.patch_tw && p.OHW < BM) : MULTI != 0;
-  const bool yt_ = YT == 2 ? p.yt != nullptr : YT != 0;
-  const bool act_ = ACT == 2 ? p.act != UR_ACT_NONE : ACT != 0;
-  const bool has_res = p.res != nullptr;
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    if (pair_ && (a & 1)) continue;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int ln = wn * WTN + a * 32 + rg * 8 + fhalf * 4;          // column inside the tile (GEMM-N space)
-      const int co_in = n0 + ln;
-      float4 bv = *reinterpret_cast<const float4*>(sbias + ln);
-      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pair_) gv = *reinterpret_cast<const float4*>(sbias + ln + 32);
-      const int lco = pair_ ? ((ln >> 6) * 32 + (ln & 31)) : ln;        // column inside the OUTPUT tile
-      const int co = c0 + lco;
-      const bool col_ok = co_in < p.Cout;
-      float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sg = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ln_) {
-        sv = *reinterpret_cast<const float4*>(scol + ln);
-        if (pair_) sg = *reinterpret_cast<const float4*>(scol + ln + 32);
-      }
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        const int lm = wm * WTM + b * 32 + mrow;
-        if (multi_) {                                  // tile spans several images: this row's own bias row
-          const int il = lm / p.OHW;
-          bv = *reinterpret_cast<const float4*>(sbias + il * BN + ln);
-          if (pair_) gv = *reinterpret_cast<const float4*>(sbias + il * BN + ln + 32);
-        }
-        float v[4], gq[4] = {0.f, 0.f, 0.f, 0.f};
-        constexpr int a1 = (FN > 1) ? 1 : 0;
-        if (ln_) {                                            // LayerNorm folded into this GEMM (see above)
-          const float mean = srow[2 * lm], rstd = srow[2 * lm + 1];
-          v[0] = rstd * (acc[a][b][rg * 4] - mean * sv.x) + bv.x;     v[1] = rstd * (acc[a][b][rg * 4 + 1] - mean * sv.y) + bv.y;
-          v[2] = rstd * (acc[a][b][rg * 4 + 2] - mean * sv.z) + bv.z; v[3] = rstd * (acc[a][b][rg * 4 + 3] - mean * sv.w) + bv.w;
-          if (pair_) {
-            gq[0] = rstd * (acc[(a + a1) % FN][b][rg * 4] - mean * sg.x) + gv.x;     gq[1] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 1] - mean * sg.y) + gv.y;
-            gq[2] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 2] - mean * sg.z) + gv.z; gq[3] = rstd * (acc[(a + a1) % FN][b][rg * 4 + 3] - mean * sg.w) + gv.w;
-          }
-        } else {
-          v[0] = acc[a][b][rg * 4] + bv.x; v[1] = acc[a][b][rg * 4 + 1] + bv.y;
-          v[2] = acc[a][b][rg * 4 + 2] + bv.z; v[3] = acc[a][b][rg * 4 + 3] + bv.w;
-          if (pair_) {
-            gq[0] = acc[(a + a1) % FN][b][rg * 4] + gv.x; gq[1] = acc[(a + a1) % FN][b][rg * 4 + 1] + gv.y;
-            gq[2] = acc[(a + a1) % FN][b][rg * 4 + 2] + gv.z; gq[3] = acc[(a + a1) % FN][b][rg * 4 + 3] + gv.w;
-          }
-        }
-        if (pair_) {
-          const float g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3];
-          if (p.act == UR_ACT_GEGLU) { v[0] *= gelu_f(g0); v[1] *= gelu_f(g1); v[2] *= gelu_f(g2); v[3] *= gelu_f(g3); }
-          else { v[0] *= g0; v[1] *= g1; v[2] *= g2; v[3] *= g3; }
-        } else if (act_) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-        const int mg = tile_row_to_m(p, m0, lm);
-        const bool ok = col_ok && mg < p.M;
-        if (yt_ && co >= p.n_split) {                                   // transposed columns (V^T) go out directly
-          if (ok) epi_store(p, gb, mg, co, v);
-          continue;
-        }
-        uint2* sp = reinterpret_cast<uint2*>(smem + lm * SROW + lco * 2);
-        if (has_res) {
-          const uint2 rv = *sp;
-          v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-          v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-        }
-        if (ok) *sp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-      }
-    }
-  }
-}
-
-// Staged epilogue body.  CLS 0 = the plain class (no pair activation, no LayerNorm consumer, one bias row per tile, no
-// transposed columns): those features are compiled out, so the executed path is short and contiguous (skipping over
-// feature blocks costs an instruction-cache miss per far branch on a cold CU).  CLS 1 = everything, decided at run time.
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, int CLS>
-__device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
-                                                int gb, unsigned char* smem, bool owner, int nimg_tile_in) {
-  constexpr int SROW = BN * 2 + 8;
-  const bool pair = CLS ? is_pair_act(p.act) : false;
-  const bool ln = CLS ? p.ln_stats != nullptr : false;
-  const bool yt = CLS ? p.yt != nullptr : false;
-  const int nimg_tile = CLS ? nimg_tile_in : 1;
-  const int c0 = pair ? (n0 >> 1) : n0;                  // first output column of this tile
-  const int ncols = pair ? BN / 2 : BN;
-  const int cmax = min(yt ? p.n_split : (pair ? p.Cout / 2 : p.Cout), c0 + ncols) - c0;     // valid output columns here
-  float* sbias = reinterpret_cast<float*>(smem + BM * SROW);                                   // [nimg_tile][BN] floats (GEMM-N order)
-  float* facc = sbias + 4 * BN;                                                                // [2][BN] fused GroupNorm sums
-  float* scol = facc + 2 * BN;                                                                 // [BN] LN fusion: column sums of W*gamma
-  float* srow = scol + BN;                                                                     // [BM][2] LN fusion: mean, rstd per row
-  const int img0 = m0 / p.OHW;
-  for (int i = threadIdx.x; i < BN * nimg_tile; i += NT) {
-    const int il = i / BN, col = i - il * BN;
-    const long long boff = gb * p.bs_bias + (p.bias_img ? (long long)min(img0 + il, p.N - 1) * p.bias_img : 0);
-    sbias[i] = (p.bias && n0 + col < p.Cout) ? p.bias[boff + n0 + col] : 0.f;
-  }
-  if (p.gn_fused)
-    for (int i = threadIdx.x; i < 2 * BN; i += NT) facc[i] = 0.f;
-  if (ln) {   // this GEMM consumes LayerNorm(x): out = rstd*(acc - mean*s[n]) + t[n]  (t arrives as the bias)
-    for (int i = threadIdx.x; i < BN; i += NT) scol[i] = n0 + i < p.Cout ? p.ln_colsum[n0 + i] : 0.f;
-    for (int r = threadIdx.x; r < BM; r += NT) {
-      const int m = min(tile_row_to_m(p, m0, r), p.M - 1);
-      float sx = 0.f, sq = 0.f;
-      for (int q = 0; q < p.ln_parts; ++q) {               // one partial per N tile of the producer GEMM (no atomics)
-        const float2 t2 = *reinterpret_cast<const float2*>(p.ln_stats + 2 * ((long long)q * p.M + m));
-        sx += t2.x; sq += t2.y;
-      }
-      const float mean = sx / p.ln_dim;
-      const float var = fmaxf(sq / p.ln_dim - mean * mean, 0.f);
-      srow[2 * r] = mean;
-      srow[2 * r + 1] = rsqrtf(var + p.ln_eps);
-    }
-  }
-  if (p.res) {                                            // residual tile -> LDS, coalesced
-    uint16_t* rb = const_cast<uint16_t*>(p.res) + gb * p.bs_r;
-    if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, true>(p, rb, p.ldr, smem, m0, p.M, c0, cmax);
-    else tile_copy<BM, BN, NT, SROW, true>(p, rb, p.ldr, smem, m0, p.M, c0, cmax);
-  }
-  __syncthreads();
-  if (owner) {
-    // lean specialisations for the common launches; everything else takes the all-run-time instance
-    const bool multi = nimg_tile > 1, hasact = p.act != UR_ACT_NONE;
-#define UR_EPI_PASS(PAIR, LN, MULTI, YT, ACT) \
-    epi_frag_pass<FM, FN, WTM, WTN, BM, BN, SROW, PAIR, LN, MULTI, YT, ACT>(p, acc, m0, n0, c0, wm, wn, lane, gb, smem, sbias, scol, srow)
-    if (CLS == 0) { if (hasact) UR_EPI_PASS(0, 0, 0, 0, 1); else UR_EPI_PASS(0, 0, 0, 0, 0); }
-    else if (!pair && ln && !multi && !yt && !hasact) UR_EPI_PASS(0, 1, 0, 0, 0);
-    else if (pair && !multi && !yt) { if (ln) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0); }
-    else UR_EPI_PASS(2, 2, 2, 2, 2);
-#undef UR_EPI_PASS
-  }
-  if (p.dbg & 16) return;
-  __syncthreads();
-  if (p.gn_fused) {
-    // Fused GroupNorm statistics of the tile just produced (exactly the bf16 values the consumer will read):
-    // thread (g, cp) sums column pair cp over row group g from LDS, row groups meet in LDS, then ONE fp64 atomic
-    // per (column, moment) per workgroup.  The host only sets gn_fused when a tile never straddles two images.
-    const int CP = ncols >> 1, NG = NT / CP, RGN = (BM + NG - 1) / NG;
-    const int cp = threadIdx.x % CP, g = threadIdx.x / CP;
-    if (g < NG && cp * 2 < cmax) {
-      const int r0 = g * RGN, r1 = p.patch_tw ? min(BM, r0 + RGN) : min(min(BM, r0 + RGN), p.M - m0);
-      float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-      for (int r = r0; r < r1; ++r) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * SROW + cp * 4);
-        const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
-        s0 += a; q0 += a * a; s1 += b; q1 += b * b;
-      }
-      atomicAdd(&facc[cp * 2], s0); atomicAdd(&facc[cp * 2 + 1], s1);
-      atomicAdd(&facc[BN + cp * 2], q0); atomicAdd(&facc[BN + cp * 2 + 1], q1);
-    }
-    __syncthreads();
-    const int ctot = pair ? p.Cout / 2 : p.Cout;
-    double* st = p.gn_stats + ((long long)(m0 / p.OHW) * p.nbatch * ctot + (long long)gb * ctot + c0) * 2;
-    for (int i = threadIdx.x; i < cmax; i += NT) {
-      atomicAdd(&st[2 * i], (double)facc[i]);
-      atomicAdd(&st[2 * i + 1], (double)facc[BN + i]);
-    }
-  }
-  if (p.row_stats) {
-    // per-row (sum, sum of squares) over this tile's columns of the bf16 values just produced: the LayerNorm statistics
-    // of the consumer GEMM.  NT/BM threads share a row; partials meet through float atomics (one pair per row per N tile).
-    constexpr int TPR = NT / BM >= 1 ? NT / BM : 1;
-    const int r = threadIdx.x / TPR, part = threadIdx.x % TPR;
-    if (r < BM) {
-      const int m = tile_row_to_m(p, m0, r);
-      const int npair = cmax >> 1, per = (npair + TPR - 1) / TPR;
-      float sx = 0.f, sq = 0.f;
-      for (int j = part * per; j < min(npair, (part + 1) * per); ++j) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * SROW + j * 4);
-        const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
-        sx += a + b; sq += a * a + b * b;
-      }
-      if (TPR >= 2) { sx += __shfl_xor(sx, 1, 64); sq += __shfl_xor(sq, 1, 64); }
-      if (TPR >= 4) { sx += __shfl_xor(sx, 2, 64); sq += __shfl_xor(sq, 2, 64); }
-      static_assert(TPR == 1 || TPR == 2 || TPR == 4, "row-stat reduction: 1, 2 or 4 threads per row (same wave)");
-      const int tn_idx = n0 / BN;
-      if (m < p.M && part == 0)
-        *reinterpret_cast<float2*>(p.row_stats + 2 * ((long long)tn_idx * p.M + m)) = make_float2(sx, sq);
-    }
-  }
-  uint16_t* yb = reinterpret_cast<uint16_t*>(p.y) + gb * p.bs_y;
-  if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, false>(p, yb, p.ldy, smem, m0, p.M, c0, cmax);
-  else tile_copy<BM, BN, NT, SROW, false>(p, yb, p.ldy, smem, m0, p.M, c0, cmax);
-}
-
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT>
-__device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
-                                               int gb, int sz, unsigned char* smem, bool owner = true) {
-  // owner: this wave holds accumulator fragments (false for the loader waves of the warp-specialised kernel,
-  // which still take part in the barriers and the tile copies)
-  const int fhalf = lane >> 5, mrow = lane & 31;
-  if (p.splitk > 1) {
-    if (!owner) return;
-    float* ws = p.ws + ((long long)(sz * p.nbatch + gb) * p.M) * p.Cout;
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        int m = tile_row_to_m(p, m0, wm * WTM + b * 32 + mrow);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
-          if (m < p.M && co < p.Cout)
-            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =
-                make_float4(acc[a][b][rg * 4], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
-        }
-      }
-    return;
-  }
-  const bool pair = is_pair_act(p.act);
-  constexpr int SROW = BN * 2 + 8;                       // staged row stride in bytes (+8 spreads the ds_write_b64 banks)
-  // per-image bias rows (time embeddings of a schedule-batched Controller): a tile covers 1 image, or up to 4 whole ones
-  const int nimg_tile = (p.bias_img && !p.patch_tw && p.OHW < BM) ? BM / p.OHW : 1;
-  const bool bias_geom_ok = !p.bias_img || p.patch_tw || (p.OHW % BM) == 0 || ((BM % p.OHW) == 0 && nimg_tile <= 4);
-  const bool staged = p.staged_ok_ && BN >= 32 && bias_geom_ok;   // host-evaluated part: bf16 y, 16-byte aligned rows, no colsum
-  if (!staged) {
-    if (owner) igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
-    return;
-  }
-  const bool plain = !pair && !p.ln_stats && nimg_tile == 1 && !p.yt;
-  if (plain) staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 0>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
-  else staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 1>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
-}
-
-template <int BM, int BN, int WM, int WN, bool G1 = false>
-__global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
-  // G1: pure GEMM (1x1, stride 1, one source, no padding): rows are plain offsets, no im2col state, no tap bookkeeping
-  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, XP = BM / 32, WP = BN / 32;
-  constexpr int STAGE = (BM + BN) * 128;
-  static_assert(WM * WN == 4 && WTM % 32 == 0 && WTN % 32 == 0, "tile/wave shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid % WM, wn = wid / WM;
-  const int gb = blockIdx.y, sz = blockIdx.z;
-
-  // XCD-aware bijective remap: XCD (id % 8) owns a contiguous run of tiles, n-tile fastest.
-  int id = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
-  const uint16_t* __restrict__ X2 = p.x2 ? p.x2 + gb * p.bs_x2 : nullptr;
-  const uint16_t* __restrict__ Wt = p.w + gb * p.bs_w;
-
-  // ---- loader geometry: thread -> (row = pass*32 + tid/8, 16-B chunk = tid%8) -----------------------
-  const int chunk = tid & 7, lrow = tid >> 3;
-  int ih0[XP], iw0[XP], nb[XP];
-  bool xok[XP];
-#pragma unroll
-  for (int i = 0; i < XP; ++i) {
-    int m = m0 + i * 32 + lrow;
-    xok[i] = m < p.M;
-    if (G1) { nb[i] = xok[i] ? m * p.ldx : 0; ih0[i] = iw0[i] = 0; continue; }    // nb = element offset of the row
-    int mm = xok[i] ? m : 0;
-    int n = mm / p.OHW, rem = mm - n * p.OHW;
-    int oh = rem / p.OW, ow = rem - oh * p.OW;
-    ih0[i] = oh * p.stride - p.pad_t;
-    iw0[i] = ow * p.stride - p.pad_l;
-    nb[i] = n * p.H;
-  }
-  long long woff[WP];
-  bool wok[WP];
-#pragma unroll
-  for (int j = 0; j < WP; ++j) {
-    int row = n0 + j * 32 + lrow;
-    wok[j] = row < p.Cout;
-    woff[j] = (long long)(wok[j] ? row : 0) * p.ldw;
-  }
-  const int Hlim = p.ups ? p.H * 2 : p.H, Wlim = p.ups ? p.W * 2 : p.W;
-
-  const int kt_begin = sz * p.nk_per_split;
-  const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
-  int kcur = kt_begin * 64 + chunk * 8;
-  int tap = 0, cch = kcur;
-  const int ntap = p.KH * p.KW;
-  if (!G1) {
-    tap = kcur / p.Cin; cch = kcur - tap * p.Cin;
-    if (p.kcm) { tap = kt_begin % ntap; cch = (kt_begin / ntap) * 64 + chunk * 8; }
-  }
-
-  uint4 xr[XP], wr[WP];
-  auto load_tile = [&]() {
-    const bool kval = kcur < p.Ktot;
-    if (G1) {
-#pragma unroll
-      for (int i = 0; i < XP; ++i) {
-        const bool v = kval && xok[i];
-        const uint4 val = *reinterpret_cast<const uint4*>(v ? X1 + nb[i] + kcur : X1);
-        xr[i] = v ? val : make_uint4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < WP; ++j) {
-        const bool v = kval && wok[j];
-        const uint4 val = *reinterpret_cast<const uint4*>(v ? Wt + woff[j] + kcur : Wt);
-        wr[j] = v ? val : make_uint4(0, 0, 0, 0);
-      }
-      kcur += 64;
-      return;
-    }
-    const int dy = (p.KW == 1) ? 0 : (tap * 11) >> 5;
-    const int dx = tap - dy * p.KW;
-    const uint16_t* src = X1;
-    int ld = p.ldx, cc = cch;
-    if (cch >= p.C1) { src = X2; ld = p.ldx2; cc = cch - p.C1; }
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      int ih = ih0[i] + dy, iw = iw0[i] + dx;
-      bool v = kval && xok[i] && (unsigned)ih < (unsigned)Hlim && (unsigned)iw < (unsigned)Wlim;
-      if (p.ups) { ih >>= 1; iw >>= 1; }
-      long long off = ((long long)(nb[i] + ih) * p.W + iw) * ld + cc;
-      const uint4* ptr = reinterpret_cast<const uint4*>(v ? src + off : src);
-      uint4 val = *ptr;
-      xr[i] = v ? val : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < WP; ++j) {
-      bool v = kval && wok[j];
-      const uint4* ptr = reinterpret_cast<const uint4*>(v ? Wt + woff[j] + kcur : Wt);
-      uint4 val = *ptr;
-      wr[j] = v ? val : make_uint4(0, 0, 0, 0);
-    }
-    kcur += 64;
-    if (p.kcm) { if (++tap == ntap) { tap = 0; cch += 64; } }
-    else { cch += 64; while (cch >= p.Cin) { cch -= p.Cin; ++tap; } }
-  };
-  auto store_tile = [&](int stage) {
-    unsigned char* xs = smem + stage * STAGE;
-    unsigned char* wsm = xs + BM * 128;
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      int row = i * 32 + lrow;
-      *reinterpret_cast<uint4*>(xs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = xr[i];
-    }
-#pragma unroll
-    for (int j = 0; j < WP; ++j) {
-      int row = j * 32 + lrow;
-      *reinterpret_cast<uint4*>(wsm + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = wr[j];
-    }
-  };
-
-  f32x16 acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  const int frow = lane & 31, fhalf = lane >> 5;
-  auto compute = [&](int stage) {
-    const unsigned char* xs = smem + stage * STAGE;
-    const unsigned char* wsm = xs + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int slot = ks * 2 + fhalf;
-      bf16x8 bfr[FM], afr[FN];
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        int row = wm * WTM + b * 32 + frow;
-        bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int a = 0; a < FN; ++a) {
-        int row = wn * WTN + a * 32 + frow;
-        afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
-    }
-  };
-
-  // ---- main loop ---------------------------------------------------------------------------------------
-  if (kt_begin < kt_end) {
-    load_tile();
-    store_tile(0);
-    __syncthreads();
-    int stage = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const bool more = kt + 1 < kt_end;
-      if (more) load_tile();
-      compute(stage);
-      if (more) store_tile(stage ^ 1);
-      __syncthreads();
-      stage ^= 1;
-    }
-  }
-
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, 256>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
-}
-
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p) {
-  const bool pair = is_pair_act(p.act);
-  const int qn = p.Cout / 4;  // quads per row in GEMM N space
-  long long total = (long long)p.nbatch * p.M * qn;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    int q = (int)(i % qn);
-    long long r = i / qn;
-    int m = (int)(r % p.M), gb = (int)(r / p.M);
-    int co_in = q * 4;
-    if (pair && (co_in & 32)) continue;  // gate quads are consumed by their 'a' partner
-    float v[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
-    for (int s = 0; s < p.splitk; ++s) {
-      const float* ws = p.ws + ((long long)(s * p.nbatch + gb) * p.M + m) * p.Cout + co_in;
-      float4 t = *reinterpret_cast<const float4*>(ws);
-      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-      if (pair) {
-        float4 u = *reinterpret_cast<const float4*>(ws + 32);
-        g[0] += u.x; g[1] += u.y; g[2] += u.z; g[3] += u.w;
-      }
-    }
-    int co = epi_act(p, gb, m, co_in, v, g);
-    if (p.colsum) {
-      int cw = pair ? p.Cout / 2 : p.Cout;
-      for (int e = 0; e < 4; ++e)
-        atomicAdd(p.colsum + ((long long)(m / p.OHW) * p.nbatch + gb) * cw + co + e, v[e] * p.colsum_scale);
-    }
-    epi_store(p, gb, m, co, v);
-  }
-}
-
-// Split-K reduce for GEMMs that take part in LayerNorm folding: one wave per output row, so the row owns its
-// LayerNorm statistics - the consumer transform rstd*(acc - mean*s[n]) is applied to the reduced sums, and the
-// producer's (sum, sumsq) of the bf16 values written goes out as ONE plane (ln_parts == 1 for the next GEMM).
-__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const ConvK p) {
-  const bool pair = is_pair_act(p.act);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int qn = p.Cout / 4;
-  for (int m = blockIdx.x * 4 + wv; m < p.M; m += gridDim.x * 4) {
-    float mean = 0.f, rstd = 1.f;
-    if (p.ln_stats) {
-      float sx = 0.f, sq = 0.f;
-      for (int q = 0; q < p.ln_parts; ++q) {
-        const float2 t2 = *reinterpret_cast<const float2*>(p.ln_stats + 2 * ((long long)q * p.M + m));
-        sx += t2.x; sq += t2.y;
-      }
-      mean = sx / p.ln_dim;
-      rstd = rsqrtf(fmaxf(sq / p.ln_dim - mean * mean, 0.f) + p.ln_eps);
-    }
-    float rsx = 0.f, rsq = 0.f;
-    for (int q = lane; q < qn; q += 64) {
-      const int co_in = q * 4;
-      if (pair && (co_in & 32)) continue;
-      float v[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
-      for (int s = 0; s < p.splitk; ++s) {
-        const float* ws = p.ws + ((long long)s * p.M + m) * p.Cout + co_in;
-        const float4 t = *reinterpret_cast<const float4*>(ws);
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-        if (pair) {
-          const float4 u = *reinterpret_cast<const float4*>(ws + 32);
-          g[0] += u.x; g[1] += u.y; g[2] += u.z; g[3] += u.w;
-        }
-      }
-      if (p.ln_stats) {
-        const float4 sc = *reinterpret_cast<const float4*>(p.ln_colsum + co_in);
-        v[0] = rstd * (v[0] - mean * sc.x); v[1] = rstd * (v[1] - mean * sc.y);
-        v[2] = rstd * (v[2] - mean * sc.z); v[3] = rstd * (v[3] - mean * sc.w);
-        if (pair) {
-          const float4 sg = *reinterpret_cast<const float4*>(p.ln_colsum + co_in + 32);
-          g[0] = rstd * (g[0] - mean * sg.x); g[1] = rstd * (g[1] - mean * sg.y);
-          g[2] = rstd * (g[2] - mean * sg.z); g[3] = rstd * (g[3] - mean * sg.w);
-        }
-      }
-      const int co = epi_act(p, 0, m, co_in, v, g);
-      if (p.res) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + (long long)m * p.ldr + co);
-        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-      }
-      const uint2 o = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.ldy + co) = o;
-      const float a0 = __uint_as_float(o.x << 16), a1 = __uint_as_float(o.x & 0xffff0000u);
-      const float a2 = __uint_as_float(o.y << 16), a3 = __uint_as_float(o.y & 0xffff0000u);
-      rsx += (a0 + a1) + (a2 + a3);
-      rsq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-    }
-    if (p.row_stats) {
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) { rsx += __shfl_xor(rsx, o, 64); rsq += __shfl_xor(rsq, o, 64); }
-      if (lane == 0) *reinterpret_cast<float2*>(p.row_stats + 2 * (long long)m) = make_float2(rsx, rsq);
-    }
-  }
-}
-
-
-// Split-K reduce that also leaves the GroupNorm statistics of what it writes (the 16x16 / 8x8 levels: every 3x3 conv
-// there is split-K, and each used to be followed by a separate statistics pass).  Block = 16 column quads x 16 row
-// lanes over 64 consecutive rows of ONE image (host guarantees OHW % 64 == 0); column sums stay in registers, the
-// row lanes meet in LDS, then one fp64 atomic per (column, moment) per block.
-__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
-  __shared__ float red[16][16][9];
-  const int qc = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int q = blockIdx.x * 16 + qc, qn = p.Cout / 4, co = q * 4;
-  const int r0 = blockIdx.y * 64;
-  float sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
-  if (q < qn) {
-    float v[4][4];
-    uint2 rv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = r0 + rl + 16 * i;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
-      for (int sp = 0; sp < p.splitk; ++sp) {
-        const float4 t = *reinterpret_cast<const float4*>(p.ws + ((long long)sp * p.M + m) * p.Cout + co);
-        v[i][0] += t.x; v[i][1] += t.y; v[i][2] += t.z; v[i][3] += t.w;
-      }
-      rv[i] = p.res ? *reinterpret_cast<const uint2*>(p.res + (long long)m * p.ldr + co) : make_uint2(0, 0);
-    }
-    const float g[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = r0 + rl + 16 * i;
-      epi_act(p, 0, m, co, v[i], g);
-      v[i][0] += __uint_as_float(rv[i].x << 16); v[i][1] += __uint_as_float(rv[i].x & 0xffff0000u);
-      v[i][2] += __uint_as_float(rv[i].y << 16); v[i][3] += __uint_as_float(rv[i].y & 0xffff0000u);
-      const uint2 o = make_uint2(pack2bf(v[i][0], v[i][1]), pack2bf(v[i][2], v[i][3]));
-      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.ldy + co) = o;
-      const float a[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
-                          __uint_as_float(o.y & 0xffff0000u)};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { sm[e] += a[e]; sq[e] += a[e] * a[e]; }
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { red[rl][qc][e] = sm[e]; red[rl][qc][4 + e] = sq[e]; }
-  __syncthreads();
-  // 128 (column quad, moment-lane) sums of 16 row lanes each, then one fp64 atomic per (column, moment)
-  if (threadIdx.x < 128) {
-    const int c = threadIdx.x >> 3, e = threadIdx.x & 7;
-    const int qq = blockIdx.x * 16 + c;
-    if (qq < qn) {
-      float a = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a += red[r][c][e];
-      double* st = p.gn_stats + ((long long)(r0 / p.OHW) * p.Cout + qq * 4) * 2;
-      atomicAdd(&st[2 * (e & 3) + (e >> 2)], (double)a);
-    }
-  }
-}
-
-// picks the reduce pass of a split-K launch (and records whether it produced the GroupNorm statistics)
-static void launch_splitk_reduce(ConvK& k, hipStream_t s) {
-  const bool pair = k.act == UR_ACT_GEGLU || k.act == UR_ACT_GATE;
-  if (k.row_stats || k.ln_stats) {
-    hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(std::min((k.M + 3) / 4, 4096)), dim3(256), 0, s, k);
-  } else if (!getenv("UR_IGEMM_NOGNRED") && k.gn_stats && !pair && k.staged_ok_ && k.nbatch == 1 && !k.yt && k.OHW % 64 == 0 && !k.patch_tw) {
-    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((k.Cout / 4 + 15) / 16, k.M / 64), dim3(256), 0, s, k);
-    k.gn_fused = 1;
-  } else {
-    long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
-    int rb = (int)std::min<long long>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
-  }
-}
-
-template <int BM, int BN, int WM, int WN>
-int launch_cfg(ConvK& k, hipStream_t s) {
-  k.tiles_m = (k.M + BM - 1) / BM;
-  k.tiles_n = (k.Cout + BN - 1) / BN;
-  const long long blocks = (long long)k.tiles_m * k.tiles_n * k.nbatch;
-  int splitk = 1;
-  if (blocks < 200 && k.nk >= 8 && k.ws) {
-    long long want = (384 + blocks - 1) / blocks;
-    long long cap_k = k.nk / 4;
-    splitk = (int)std::min<long long>(std::min<long long>(want, cap_k), 16);
-    long long need = (long long)splitk * k.nbatch * k.M * k.Cout * 4;
-    while (splitk > 1 && need > (long long)k.ws_bytes_) { --splitk; need = (long long)splitk * k.nbatch * k.M * k.Cout * 4; }
-    if (splitk < 1) splitk = 1;
-  }
-  k.splitk = splitk;
-  k.nk_per_split = (k.nk + splitk - 1) / splitk;
-  k.splitk = (k.nk + k.nk_per_split - 1) / k.nk_per_split;
-  if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }     // row-stat planes this launch writes
-  k.gn_fused = k.gn_stats && k.staged_ok_ && k.splitk == 1 && BN >= 32 && (k.OHW % BM) == 0;
-  constexpr int lds = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
-  static const bool no_g1 = getenv("UR_IGEMM_NOG1") != nullptr;
-  const bool g1 = !no_g1 && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.pad_t == 0 && k.pad_l == 0 && k.OH == k.H && k.OW == k.W &&
-                  (long long)k.M * k.ldx + k.Ktot < (1ll << 31);
-  if (g1) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), lds, s, k);
-  else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), lds, s, k);
-  if (k.splitk > 1) launch_splitk_reduce(k, s);
-  return ur::check_launch("ur_conv2d_nhwc");
-}
-
-
-// =====================================================================================================================
-// v2 main loop: LDS-DMA (global_load_lds_dwordx4) into an NST-deep ring, counted vmcnt, one raw s_barrier per K tile.
-//   * each wave-instruction lands 1 KiB = 8 rows x 128 B lane-linearly; the XOR swizzle therefore lives on the
-//     SOURCE address (lane's physical slot ps reads logical chunk ps ^ ((row>>1)&7) of its row) - same 128-B line,
-//     so coalescing is unchanged and the fragment reads stay conflict-free;
-//   * padded / out-of-range pieces read a 16-byte zero page instead of being predicated (every wave issues the
-//     same number of DMA ops per tile, so one immediate vmcnt(N) is right for all waves);
-//   * no VGPR staging: the ring is NST-1 tiles ahead of the MFMAs (HBM/L2 latency hidden across barriers).
-template <int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) {
-  constexpr int NT = WM * WN * 64, RPP = NT / 8;                  // threads; tile rows covered by one loader pass
-  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
-  constexpr int XP = BM / RPP, WP = (BN + RPP - 1) / RPP, NLD = XP + WP;
-  constexpr int STAGE = (BM + BN) * 128;
-  static_assert(BM % RPP == 0 && WTM % 32 == 0 && WTN % 32 == 0 && RPP % 16 == 0, "tile/wave shape");
-  static_assert(BN % RPP == 0 || (BN % RPP) * 2 == RPP, "partial W pass must be exactly half a pass");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid % WM, wn = wid / WM;
-  const int gb = blockIdx.y, sz = blockIdx.z;
-  int id = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
-  const uint16_t* __restrict__ X2 = p.x2 ? p.x2 + gb * p.bs_x2 : nullptr;
-  const uint16_t* __restrict__ Wt = p.w + gb * p.bs_w;
-  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
-
-  const int lrow = tid >> 3;                                       // row inside a loader pass
-  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);                 // logical 16-B K chunk this lane fetches
-  int ih0[XP], iw0[XP], nb[XP];
-  bool xok[XP];
-#pragma unroll
-  for (int i = 0; i < XP; ++i) {
-    int m = m0 + i * RPP + lrow;
-    xok[i] = m < p.M;
-    int mm = xok[i] ? m : 0;
-    int n = mm / p.OHW, rem = mm - n * p.OHW;
-    int oh = rem / p.OW, ow = rem - oh * p.OW;
-    ih0[i] = oh * p.stride - p.pad_t;
-    iw0[i] = ow * p.stride - p.pad_l;
-    nb[i] = n * p.H;
-  }
-  long long woff[WP];
-  bool wok[WP];
-  int wrow_lds[WP];
-#pragma unroll
-  for (int j = 0; j < WP; ++j) {
-    int lr = j * RPP + lrow;
-    if (lr >= BN) lr -= RPP / 2;          // half pass: the upper waves re-fetch the lower half (identical bytes)
-    wrow_lds[j] = lr;
-    int row = n0 + lr;
-    wok[j] = row < p.Cout;
-    woff[j] = (long long)(wok[j] ? row : 0) * p.ldw;
-  }
-  const int Hlim = p.ups ? p.H * 2 : p.H, Wlim = p.ups ? p.W * 2 : p.W;
-
-  const int kt_begin = sz * p.nk_per_split;
-  const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
-  int kcur = kt_begin * 64 + chunk * 8;
-  int tap = kcur / p.Cin, cch = kcur - tap * p.Cin;
-  const int ntap = p.KH * p.KW;
-  if (p.kcm) { tap = kt_begin % ntap; cch = (kt_begin / ntap) * 64 + chunk * 8; }
-
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  auto issue_tile = [&](int stage) {
-    unsigned char* xs = smem + stage * STAGE;
-    unsigned char* wsm = xs + BM * 128;
-    const bool kval = kcur < p.Ktot;
-    const int dy = (p.KW == 1) ? 0 : (tap * 11) >> 5;
-    const int dx = tap - dy * p.KW;
-    const uint16_t* src = X1;
-    int ld = p.ldx, cc = cch;
-    if (cch >= p.C1) { src = X2; ld = p.ldx2; cc = cch - p.C1; }
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      int ih = ih0[i] + dy, iw = iw0[i] + dx;
-      bool v = kval && xok[i] && (unsigned)ih < (unsigned)Hlim && (unsigned)iw < (unsigned)Wlim;
-      if (p.ups) { ih >>= 1; iw >>= 1; }
-      long long off = ((long long)(nb[i] + ih) * p.W + iw) * ld + cc;
-      const uint16_t* g = v ? src + off : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(xs + (i * RPP + wid * 8) * 128), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < WP; ++j) {
-      bool v = kval && wok[j];
-      const uint16_t* g = v ? Wt + woff[j] + kcur : zero;
-      const int base_row = wrow_lds[j] - (lane >> 3);               // wave-uniform first row of this 1-KiB piece
-      if (p.dbg & 128) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wsm + base_row * 128), 16, 0, 2);   // nt: stream past L1
-      else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wsm + base_row * 128), 16, 0, 0);
-    }
-    kcur += 64;
-    if (p.kcm) { if (++tap == ntap) { tap = 0; cch += 64; } }
-    else { cch += 64; while (cch >= p.Cin) { cch -= p.Cin; ++tap; } }
-  };
-
-  f32x16 acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  const int frow = lane & 31, fhalf = lane >> 5;
-  auto compute = [&](int stage) {
-    const unsigned char* xs = smem + stage * STAGE;
-    const unsigned char* wsm = xs + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int slot = ks * 2 + fhalf;
-      bf16x8 bfr[FM], afr[FN];
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        int row = wm * WTM + b * 32 + frow;
-        bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int a = 0; a < FN; ++a) {
-        int row = wn * WTN + a * 32 + frow;
-        afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
-    }
-  };
-
-  // ---- ring: tile t lives in stage t % NST; up to NST-1 tiles are in flight ahead of the MFMAs -----------------------
-  const int ntile = (p.dbg & 8) ? 0 : kt_end - kt_begin;
-  if (ntile > 0) {
-    int issued = 0;
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-      if (issued < ntile) { issue_tile(s); ++issued; }
-    // wait for tile 0
-    if (issued >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST - 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int cs = 0, is = (NST - 1) % NST;
-    for (int t = 0; t < ntile; ++t) {
-      const bool more = issued < ntile;
-      if (more) { if (!(p.dbg & 1)) issue_tile(is); ++issued; is = (is + 1 == NST) ? 0 : is + 1; }
-      if (!(p.dbg & 2)) compute(cs);
-      cs = (cs + 1 == NST) ? 0 : cs + 1;
-      // tile t+1 must have landed before anyone reads it: all but the newest (NST-2) tiles' DMAs retired
-      if (issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST - 2)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-  }
-  if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.y)[0] = 1.f; return; }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
-}
-
-// Pure-GEMM specialisation of the LDS-DMA ring (1x1 / Linear, single source): row base offsets are 32-bit element
-// offsets and nothing else is kept per row, which leaves room for 256 x 256 tiles (128 accumulator registers per wave).
-// Large-N GEMMs (GEGLU, fused QKV) are L2->CU ingest bound: at 128 x 128 tiles every flop costs 1/64 B of ingest,
-// at 256 x 256 half of that.
-template <int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
-  constexpr int NT = WM * WN * 64, RPP = NT / 8;
-  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
-  constexpr int XP = BM / RPP, WP = BN / RPP, NLD = XP + WP;
-  constexpr int STAGE = (BM + BN) * 128;
-  static_assert(BM % RPP == 0 && BN % RPP == 0 && WTM % 32 == 0 && WTN % 32 == 0 && RPP % 16 == 0, "tile/wave shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid % WM, wn = wid / WM;
-  const int gb = blockIdx.y;
-  int id = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
-  const uint16_t* __restrict__ Wt = p.w + gb * p.bs_w;
-  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
-  const int lrow = tid >> 3;
-  const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
-  int xoff[XP], woff[WP];
-#pragma unroll
-  for (int i = 0; i < XP; ++i) { const int m = m0 + i * RPP + lrow; xoff[i] = m < p.M ? m * p.ldx + chunk * 8 : -1; }
-#pragma unroll
-  for (int j = 0; j < WP; ++j) { const int r = n0 + j * RPP + lrow; woff[j] = r < p.Cout ? r * p.ldw + chunk * 8 : -1; }
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  int kbase = 0;
-  auto issue_tile = [&](int stage) {
-    unsigned char* xs = smem + stage * STAGE;
-    unsigned char* wsm = xs + BM * 128;
-    const bool kval = kbase + chunk * 8 < p.Ktot;
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      const uint16_t* g = (kval && xoff[i] >= 0) ? X1 + xoff[i] + kbase : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(xs + (i * RPP + wid * 8) * 128), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < WP; ++j) {
-      const uint16_t* g = (kval && woff[j] >= 0) ? Wt + woff[j] + kbase : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wsm + (j * RPP + wid * 8) * 128), 16, 0, 0);
-    }
-    kbase += 64;
-  };
-  f32x16 acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-  const int frow = lane & 31, fhalf = lane >> 5;
-  const int ntile = p.nk;
-  int issued = 0;
-#pragma unroll
-  for (int s = 0; s < NST - 1; ++s)
-    if (issued < ntile) { issue_tile(s); ++issued; }
-  if (NST >= 3 && issued >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int cs = 0, is = (NST - 1) % NST;
-  for (int t = 0; t < ntile; ++t) {
-    if (issued < ntile) { issue_tile(is); ++issued; is = (is + 1 == NST) ? 0 : is + 1; }
-    const unsigned char* xs = smem + cs * STAGE;
-    const unsigned char* wsm = xs + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int slot = ks * 2 + fhalf;
-      bf16x8 bfr[FM], afr[FN];
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        const int row = wm * WTM + b * 32 + frow;
-        bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int a = 0; a < FN; ++a) {
-        const int row = wn * WTN + a * 32 + frow;
-        afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int b = 0; b < FM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
-    }
-    cs = (cs + 1 == NST) ? 0 : cs + 1;
-    if (NST >= 3 && issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
-}
-
-template <int BM, int BN, int WM, int WN, int NST>
-int launch_gemm(ConvK& k, hipStream_t s) {
-  k.tiles_m = (k.M + BM - 1) / BM;
-  k.tiles_n = (k.Cout + BN - 1) / BN;
-  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
-  k.splitk = 1;
-  k.nk_per_split = k.nk;
-  k.gn_fused = k.gn_stats && k.staged_ok_ && (k.OHW % BM) == 0;
-  constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = BM * (BN * 2 + 8) + 7 * BN * 4 + BM * 8;
-  constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k);
-  return ur::check_launch("ur_conv2d_nhwc");
-}
-
-template <int BM, int BN, int WM, int WN, int NST>
-int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
-  k.tiles_m = (k.M + BM - 1) / BM;
-  k.tiles_n = (k.Cout + BN - 1) / BN;
-  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
-  const long long blocks = (long long)k.tiles_m * k.tiles_n * k.nbatch;
-  int splitk = 1;
-  if (blocks < min_blocks && k.nk >= 8 && k.ws && !k.row_stats && !k.ln_stats) {
-    long long want = (256 + blocks - 1) / blocks;
-    splitk = (int)std::min<long long>(std::min<long long>(want, k.nk / 4), 16);
-    while (splitk > 1 && (long long)splitk * k.nbatch * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
-    if (splitk < 1) splitk = 1;
-  }
-  k.nk_per_split = (k.nk + splitk - 1) / splitk;
-  k.splitk = (k.nk + k.nk_per_split - 1) / k.nk_per_split;
-  k.gn_fused = k.gn_stats && k.staged_ok_ && k.splitk == 1 && BN >= 32 && (k.OHW % BM) == 0;
-  constexpr int lds = NST * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, WM, WN, NST>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
-  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, WM, WN, NST>), grid, dim3(WM * WN * 64), lds, s, k);
-  if (k.splitk > 1) launch_splitk_reduce(k, s);
-  return ur::check_launch("ur_conv2d_nhwc");
-}
-
-
-// =====================================================================================================================
-// Halo-tile 3x3 convolution (stride 1, pad 1, optional nearest-2x upsampled input).
-// The L2 -> CU ingest path, not the MFMA pipe, bounds the implicit GEMM (about 13 B/clk/CU: ~8 KB in flight against
-// ~600 cycles of L2 latency; LDS-DMA does not allocate in L1), and the tap-major loaders re-fetch every input pixel
-// 9 times.  Here a workgroup owns an 8 x 32 pixel output patch of ONE image: per 64-channel chunk the (8+2) x (32+2)
-// input patch is DMA'd into LDS once (double-buffered across chunks, spread over the first six taps of the previous
-// chunk) and the nine taps read their B fragments out of it at a constant row offset; only the weight tile streams per
-// K tile (3-stage ring).  Ingest per K tile drops from (256+BN)*128 B to ~BN*128 B + 5 KB.
-// A fragment is one 32-pixel patch row, so its LDS rows are consecutive for every tap and the (row>>1)&7 slot swizzle
-// stays conflict-free (tools/lds_conflicts.py model; a 16x16 patch would be 2-way conflicted on every tap).
-template <int TH, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) {
-  constexpr int NW = WM * WN, TW = 32, BM = TH * TW, PW = TW + 2, HPIX = (TH + 2) * PW;   // 340 (TH=8) / 204 (TH=4) halo pixels
-  constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);                              // tap slots that carry a halo piece
-  constexpr int HPIECES = HSLOTS * NW, HBYTES = HPIECES * 1024;   // surplus pieces are never read (zero fill)
-  constexpr int WBYTES = BN * 128, WPIECES = BN / 8, WPW = (WPIECES + NW - 1) / NW;   // weight pieces per wave per tile
-  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = NW * 64;
-  static_assert((NW == 8 || NW == 4) && WTM % 32 == 0 && WTN % 32 == 0 && HSLOTS <= 8, "wave layout");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const hbuf = smem;                      // 2 halo patches
-  unsigned char* const wring = smem + 2 * HBYTES;        // 3 weight tiles
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid % WM, wn = wid / WM;
-  const int sz = blockIdx.y;
-  int id = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = id % p.tiles_n, tmi = id / p.tiles_n;
-  const int tiles_x = p.OW / TW, tiles_y = p.OH / TH;
-  const int tx = tmi % tiles_x, ty = (tmi / tiles_x) % tiles_y, img = tmi / (tiles_x * tiles_y);
-  const int n0 = tn * BN;
-  const int m0 = img * p.OHW + ty * TH * p.OW + tx * TW;         // first output pixel of the patch
-
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const uint16_t* __restrict__ X1 = p.x;
-  const uint16_t* __restrict__ X2 = p.x2;
-  const uint16_t* __restrict__ Wt = p.w;
-  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
-  const int lr = lane >> 3, ps = lane & 7;
-  // Every piece this wave issues has index == wid (mod NW, NW even), so its rows share one parity pattern and the lane's logical
-  // 16-byte K chunk is the same for all of them: physical slot ps holds chunk ps ^ ((row>>1)&7), row = 8*piece + lr.
-  const int chunk = ps ^ ((((wid & 1) << 2) + (lr >> 1)) & 7);
-
-  // input-pixel index of this lane for the six halo pieces (tap slots 0..5) this wave issues per chunk; -1 = zero fill
-  int hpix[HSLOTS];
-#pragma unroll
-  for (int t = 0; t < HSLOTS; ++t) {
-    const int hr = (t * NW + wid) * 8 + lr;
-    const int hy = hr / PW, hx = hr - hy * PW;
-    int iy = ty * TH - 1 + hy, ix = tx * TW - 1 + hx;               // coordinates in the (possibly upsampled) input
-    const bool v = hr < HPIX && (unsigned)iy < (unsigned)p.OH && (unsigned)ix < (unsigned)p.OW;
-    if (p.ups) { iy >>= 1; ix >>= 1; }
-    hpix[t] = v ? (img * p.H + iy) * p.W + ix : -1;
-  }
-  int woff[WPW];
-#pragma unroll
-  for (int i = 0; i < WPW; ++i) {
-    const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;     // surplus slot: repeat this wave's first piece
-    const int row = n0 + qq * 8 + lr;
-    woff[i] = row < p.Cout ? row * p.ldw : -1;
-  }
-  // blockIdx.y splits the channel-chunk range (few-tile layers: tiles * splits <= one round of CUs)
-  const int cps = p.nk_per_split / 9, c_begin = sz * cps, nchunk = min(p.nk / 9, c_begin + cps) - c_begin;
-  const int nk = nchunk * 9, kt0 = c_begin * 9;
-
-  auto issue_w = [&](int kt) {
-    unsigned char* st = wring + (kt % 3) * WBYTES;
-#pragma unroll
-    for (int i = 0; i < WPW; ++i) {
-      const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
-      const uint16_t* g = woff[i] >= 0 ? Wt + woff[i] + (kt0 + kt) * 64 + chunk * 8 : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + qq * 1024), 16, 0, 0);
-    }
-  };
-  auto issue_h = [&](int c, int t) {                                // halo piece (t*8 + wid) of chunk c
-    const int q = t * NW + wid;
-    int cc = (c_begin + c) * 64 + chunk * 8;
-    const uint16_t* src = X1;
-    int ld = p.ldx;
-    if (cc >= p.C1) { src = X2; ld = p.ldx2; cc -= p.C1; }
-    const uint16_t* g = hpix[t] >= 0 ? src + hpix[t] * ld + cc : zero;
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(hbuf + (c & 1) * HBYTES + q * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-  const int frow = lane & 31, fhalf = lane >> 5;
-
-  // ---- prologue: whole halo of chunk 0, weight tiles 0 and 1 ------------------------------------------------------------
-#pragma unroll
-  for (int t = 0; t < HSLOTS; ++t) issue_h(0, t);
-  issue_w(0);
-  if (nk > 1) {
-    issue_w(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-
-  for (int kt = 0, c = 0, tap = 0; kt < nk; ++kt) {
-    const bool more_w = kt + 2 < nk;
-    const bool more_h = tap < HSLOTS && c + 1 < nchunk;
-    if (more_w) issue_w(kt + 2);
-    if (more_h) {
-#pragma unroll
-      for (int t = 0; t < HSLOTS; ++t)                               // hpix[] must be indexed statically
-        if (tap == t) issue_h(c + 1, t);
-    }
-    // ---- MFMAs of K tile kt: B fragments = patch rows shifted by the tap, A fragments = weight tile -------------------
-    {
-      const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
-      const unsigned char* hb = hbuf + (c & 1) * HBYTES;
-      const unsigned char* wsm = wring + (kt % 3) * WBYTES;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int slot = ks * 2 + fhalf;
-        bf16x8 bfr[FM], afr[FN];
-#pragma unroll
-        for (int b = 0; b < FM; ++b) {
-          const int hrow = (wm * FM + b + dy) * PW + dx + frow;
-          bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int a = 0; a < FN; ++a) {
-          const int row = wn * WTN + a * 32 + frow;
-          afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int a = 0; a < FN; ++a)
-#pragma unroll
-          for (int b = 0; b < FM; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
-      }
-    }
-    // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
-    if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
-    else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-    else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (++tap == 9) { tap = 0; ++c; }
-  }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
-}
-
-template <int TH, int BN, int WM, int WN>
-int launch_halo(ConvK& k, hipStream_t s) {
-  constexpr int NW = WM * WN, BM = TH * 32, HPIX = (TH + 2) * 34, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
-  constexpr int HBYTES = HSLOTS * NW * 1024;
-  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = BM * (BN * 2 + 8) + 7 * BN * 4 + BM * 8;
-  constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  k.tiles_m = k.N * (k.OH / TH) * (k.OW / 32);
-  k.tiles_n = (k.Cout + BN - 1) / BN;
-  const int nchunk = k.nk / 9;
-  const long long tiles = (long long)k.tiles_m * k.tiles_n;
-  int splitk = 1;
-  static const bool no_hsplit = getenv("UR_IGEMM_NOHSPLIT") != nullptr;
-  if (!no_hsplit && tiles <= 128 && k.ws && !k.colsum) {     // <= half a round of CUs: split the chunk range, reduce in a second pass
-    splitk = (int)std::min<long long>(256 / tiles, std::max(1, nchunk / 2));
-    while (splitk > 1 && (long long)splitk * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
-  }
-  const int cps = (nchunk + splitk - 1) / splitk;
-  k.splitk = (nchunk + cps - 1) / cps;
-  k.nk_per_split = cps * 9;
-  if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
-  k.patch_tw = 32;
-  k.gn_fused = k.gn_stats != nullptr && k.splitk == 1;     // a patch never leaves its image
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k);
-  if (k.splitk > 1) {
-    k.patch_tw = 0;                                        // the partial planes are plain [M][Cout]
-    launch_splitk_reduce(k, s);
-  }
-  return ur::check_launch("ur_conv2d_nhwc");
-}
-
-// =====================================================================================================================
-// Whole-image halo tiles for the small feature maps (16 x 16: one image per tile; 8 x 8: four images per tile; BM = 256).
-// Same idea as igemm_halo_kernel - the input patch (with its zero border) is DMA'd into LDS once per 64-channel chunk and
-// the nine taps read shifted fragments from it - but here the tile is TH x TW x NIMG pixels of WHOLE images, so tile rows
-// are contiguous in M (plain epilogue / split-K paths apply), and the K loop is split over channel chunks (blockIdx.y)
-// because these layers have few tiles and K = 9 x 1280..2560.  A 32-pixel fragment spans several image rows; the slot
-// swizzle f(row) = ((row_in_image >> 1) - halo_y) & 7 keeps its ds_read_b128 conflict-free for both shapes
-// (searched with tools/lds_conflicts.py), at the price of a per-piece source chunk on the DMA side.
-template <int TH, int TW, int NIMG, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK p) {
-  constexpr int NW = WM * WN, BM = TH * TW * NIMG, PW = TW + 2, HP = (TH + 2) * PW, HPIX = HP * NIMG;
-  constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
-  constexpr int HPIECES = HSLOTS * NW, HBYTES = HPIECES * 1024;
-  constexpr int WBYTES = BN * 128, WPIECES = BN / 8, WPW = (WPIECES + NW - 1) / NW;
-  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = NW * 64;
-  static_assert(BM == 256 && NW == 8 && WTM % 32 == 0 && WTN % 32 == 0 && HSLOTS <= 8, "tile shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const hbuf = smem;
-  unsigned char* const wring = smem + 2 * HBYTES;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid % WM, wn = wid / WM;
-  const int sz = blockIdx.y;
-  int id = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = id % p.tiles_n, tmi = id / p.tiles_n;
-  const int n0 = tn * BN, img0 = tmi * NIMG, m0 = tmi * BM;
-
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const uint16_t* __restrict__ X1 = p.x;
-  const uint16_t* __restrict__ X2 = p.x2;
-  const uint16_t* __restrict__ Wt = p.w;
-  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
-  const int lr = lane >> 3, ps = lane & 7;
-
-  // halo pieces this wave issues per chunk: input pixel (or -1 = zero border) and the lane's logical 16-byte chunk
-  int hpix[HSLOTS], hchk[HSLOTS];
-#pragma unroll
-  for (int t = 0; t < HSLOTS; ++t) {
-    const int hr = (t * NW + wid) * 8 + lr;
-    const int im = hr / HP, rin = hr - im * HP, hy = rin / PW, hx = rin - hy * PW;
-    const int iy = hy - 1, ix = hx - 1;
-    const bool v = hr < HPIX && img0 + im < p.N && (unsigned)iy < (unsigned)TH && (unsigned)ix < (unsigned)TW;
-    hpix[t] = v ? ((img0 + im) * TH + iy) * TW + ix : -1;
-    hchk[t] = ps ^ (((rin >> 1) - hy) & 7);
-  }
-  const int wchunk = ps ^ ((((wid & 1) << 2) + (lr >> 1)) & 7);      // weight tile keeps the (row>>1)&7 swizzle
-  int woff[WPW];
-#pragma unroll
-  for (int i = 0; i < WPW; ++i) {
-    const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
-    const int row = n0 + qq * 8 + lr;
-    woff[i] = row < p.Cout ? row * p.ldw : -1;
-  }
-  const int nchunk_all = p.nk / 9, cps = p.nk_per_split / 9;
-  const int c_begin = sz * cps, c_end = min(nchunk_all, c_begin + cps);
-  const int nchunk = c_end - c_begin, nk = nchunk * 9, kt0 = c_begin * 9;
-
-  auto issue_w = [&](int kt) {
-    unsigned char* st = wring + (kt % 3) * WBYTES;
-#pragma unroll
-    for (int i = 0; i < WPW; ++i) {
-      const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
-      const uint16_t* g = woff[i] >= 0 ? Wt + woff[i] + (kt0 + kt) * 64 + wchunk * 8 : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + qq * 1024), 16, 0, 0);
-    }
-  };
-  auto issue_h = [&](int c, int t) {                                // c = chunk index local to this split
-    const int q = t * NW + wid;
-    int cc = (c_begin + c) * 64 + hchk[t] * 8;
-    const uint16_t* src = X1;
-    int ld = p.ldx;
-    if (cc >= p.C1) { src = X2; ld = p.ldx2; cc -= p.C1; }
-    const uint16_t* g = hpix[t] >= 0 ? src + hpix[t] * ld + cc : zero;
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(hbuf + (c & 1) * HBYTES + q * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[FN][FM];
-#pragma unroll
-  for (int a = 0; a < FN; ++a)
-#pragma unroll
-    for (int b = 0; b < FM; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-  const int frow = lane & 31, fhalf = lane >> 5;
-  // this lane's pixel in each of the wave's FM fragments: halo row (tap 0,0) and halo y
-  int hrow0[FM], hin0[FM], hy0[FM];
-#pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    const int pix = wm * WTM + b * 32 + frow;
-    const int im = pix / (TH * TW), r = pix - im * (TH * TW), y = r / TW, x = r - y * TW;
-    hin0[b] = y * PW + x;
-    hrow0[b] = im * HP + hin0[b];
-    hy0[b] = y;
-  }
-
-#pragma unroll
-  for (int t = 0; t < HSLOTS; ++t) issue_h(0, t);
-  issue_w(0);
-  if (nk > 1) {
-    issue_w(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-
-  for (int kt = 0, c = 0, tap = 0; kt < nk; ++kt) {
-    const bool more_w = kt + 2 < nk;
-    const bool more_h = tap < HSLOTS && c + 1 < nchunk;
-    if (more_w) issue_w(kt + 2);
-    if (more_h) {
-#pragma unroll
-      for (int t = 0; t < HSLOTS; ++t)
-        if (tap == t) issue_h(c + 1, t);
-    }
-    {
-      const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
-      const unsigned char* hb = hbuf + (c & 1) * HBYTES;
-      const unsigned char* wsm = wring + (kt % 3) * WBYTES;
-      int hro[FM], hsw[FM];
-#pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        hro[b] = (hrow0[b] + dy * PW + dx) * 128;
-        hsw[b] = (((hin0[b] + dy * PW + dx) >> 1) - (hy0[b] + dy)) & 7;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int slot = ks * 2 + fhalf;
-        bf16x8 bfr[FM], afr[FN];
-#pragma unroll
-        for (int b = 0; b < FM; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hro[b] + ((slot ^ hsw[b]) << 4));
-#pragma unroll
-        for (int a = 0; a < FN; ++a) {
-          const int row = wn * WTN + a * 32 + frow;
-          afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int a = 0; a < FN; ++a)
-#pragma unroll
-          for (int b = 0; b < FM; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
-      }
-    }
-    if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
-    else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-    else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (++tap == 9) { tap = 0; ++c; }
-  }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
-}
-
-template <int TH, int TW, int NIMG, int BN, int WM, int WN>
-int launch_halo_img(ConvK& k, hipStream_t s) {
-  constexpr int NW = WM * WN, BM = TH * TW * NIMG, HPIX = (TH + 2) * (TW + 2) * NIMG, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
-  constexpr int HBYTES = HSLOTS * NW * 1024;
-  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = BM * (BN * 2 + 8) + 7 * BN * 4 + BM * 8;
-  constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  static_assert(lds <= 160 * 1024, "LDS budget");
-  k.tiles_m = (k.N + NIMG - 1) / NIMG;
-  k.tiles_n = (k.Cout + BN - 1) / BN;
-  const int nchunk = k.nk / 9;
-  const long long tiles = (long long)k.tiles_m * k.tiles_n;
-  int splitk = 1;
-  if (tiles < 200 && k.ws) {      // one workgroup per CU: split the chunk range so that tiles * splits <= 256 (a single round)
-    splitk = (int)std::min<long long>(std::max<long long>(256 / tiles, 1), std::max(1, nchunk / 2));
-    while (splitk > 1 && (long long)splitk * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
-  }
-  const int cps = (nchunk + splitk - 1) / splitk;
-  k.splitk = (nchunk + cps - 1) / cps;
-  k.nk_per_split = cps * 9;
-  if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
-  k.gn_fused = k.gn_stats && k.splitk == 1 && (k.OHW % BM) == 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k);
-  if (k.splitk > 1) launch_splitk_reduce(k, s);
-  return ur::check_launch("ur_conv2d_nhwc");
-}
 
 int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   k.patch_tw = 0;
@@ -1521,47 +47,23 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
     static const bool old_w = getenv("UR_IGEMM_OLDW") != nullptr;
     bool use160 = ok160 && (!ok128 || (!old_w && eff(tm8 * (k.Cout / 160)) >= eff(tm8 * (k.Cout / 128))));
     const long long tiles8 = tm8 * (use160 ? k.Cout / 160 : k.Cout / 128);
-    static const bool no_h4 = getenv("UR_IGEMM_H4") == nullptr;   // opt-in: measured slightly slower (weight ingest per flop doubles)
-    if (!no_h4 && tiles8 < 224 && k.OH % 4 == 0 && ok160) {
-      const long long tiles4 = (long long)k.N * (k.OH / 4) * (k.OW / 32) * (k.Cout / 160);
-      if (tiles4 >= 192) return launch_halo<4, 160, 4, 1>(k, s);
-    }
     if ((ok128 || ok160) && tiles8 >= 64) {
-      if (use160) return launch_halo<8, 160, 8, 1>(k, s);
-      return launch_halo<8, 128, 4, 2>(k, s);
+      if (use160) return urk::halo_8x32_160(&k, s);
+      return urk::halo_8x32_128(&k, s);
     }
   }
   static const bool no_himg = getenv("UR_IGEMM_NOHIMG") != nullptr;
   if (!no_himg && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && k.staged_ok_ && !pair && k.nbatch == 1 && !k.ups &&
       k.OH == k.H && k.OW == k.W && !k.yt && k.Cout % 128 == 0 && k.nk >= 36) {
-    if (k.OH == 16 && k.OW == 16) return launch_halo_img<16, 16, 1, 128, 4, 2>(k, s);
+    if (k.OH == 16 && k.OW == 16) return urk::himg_16x16(&k, s);
     if (k.OH == 8 && k.OW == 8 && k.N % 4 == 0) {
-      static const bool n64 = getenv("UR_IGEMM_HIMG64") != nullptr;
-      if (n64) return launch_halo_img<8, 8, 4, 64, 8, 1>(k, s);
-      return launch_halo_img<8, 8, 4, 128, 4, 2>(k, s);
+      return urk::himg_8x8x4(&k, s);
     }
-  }
-  static const int sm_exp = getenv("UR_IGEMM_SM") ? atoi(getenv("UR_IGEMM_SM")) : 0;
-  if (sm_exp && !pair && k.KH == 1 && k.Cout % 128 == 0) {
-    if (sm_exp == 1) { k.ws = nullptr; return launch_cfg<128, 128, 2, 2>(k, s); }
-    if (sm_exp == 2) return launch_cfg<64, 128, 2, 2>(k, s);
-    if (sm_exp == 3) return launch_glds<64, 128, 2, 2, 3>(k, s, 0);
-    if (sm_exp == 4) return launch_glds<128, 128, 2, 2, 3>(k, s, 0);
-    if (sm_exp == 5) return launch_cfg<64, 64, 2, 2>(k, s);
-    if (sm_exp == 6) return launch_glds<64, 128, 2, 2, 4>(k, s, 0);
-    if (sm_exp == 7) return launch_glds<64, 64, 2, 2, 4>(k, s, 0);
-    if (sm_exp == 8 && k.Cout % 160 == 0) return launch_cfg<128, 160, 4, 1>(k, s);
-    if (sm_exp == 9) return launch_cfg<128, 64, 2, 2>(k, s);
-  }
-  static const int exp_mode = getenv("UR_IGEMM_EXP") ? atoi(getenv("UR_IGEMM_EXP")) : 0;
-  if (exp_mode && k.KH == 1 && k.nk <= exp_mode && !pair && k.Cout > 64) {      // short-K GEMMs: 2 workgroups per CU
-    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_glds<128, 160, 4, 1, 2>(k, s, 0);
-    return launch_glds<128, 128, 2, 2, 2>(k, s, 0);
   }
   static const bool no_g256 = getenv("UR_IGEMM_NOG256") != nullptr;
   if (!no_g256 && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.staged_ok_ && k.Cout % 256 == 0 && !k.yt && (k.act == UR_ACT_GEGLU || k.act == UR_ACT_GATE) &&
       (long long)((k.M + 255) / 256) * (k.Cout / 256) * k.nbatch >= 200 && (long long)k.M * k.ldx < (1ll << 31))
-    return launch_gemm<256, 256, 4, 2, 2>(k, s);
+    return urk::gemm_256x256(&k, s);
   static const bool force_v1 = getenv("UR_IGEMM_V1") != nullptr;
   // short-K GEMMs (<= 10 K tiles: per-workgroup prologue/epilogue latency dominates): 128-row tiles, 2 workgroups per CU
   const bool use_v1 = force_v1 || (k.KH == 1 && k.nk <= 10);
@@ -1569,33 +71,29 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   static const bool no_t64 = getenv("UR_IGEMM_NOT64") != nullptr;
   if (!no_t64 && k.KH == 1 && !pair && k.Cout > 64) {
     // too few 128 x 128 tiles to fill 256 CUs and K too short for split-K to pay for its reduce pass: 64 x 64 tiles
-    if (blocks128 < 200 && k.nk <= 24) return launch_cfg<64, 64, 2, 2>(k, s);
+    if (blocks128 < 200 && k.nk <= 24) return urk::v1_64x64(&k, s);
     // 1 < tiles/CU < 2 at 128 x 128: halve the N tile so every CU gets the same work
-    if (use_v1 && blocks128 > 256 && blocks128 < 400 && k.Cout % 128 == 0) return launch_cfg<128, 64, 2, 2>(k, s);
+    if (use_v1 && blocks128 > 256 && blocks128 < 400 && k.Cout % 128 == 0) return urk::v1_128x64(&k, s);
   }
   if (use_v1) {
-    if (pair) return launch_cfg<128, 128, 2, 2>(k, s);  // a|g 32-row blocks must sit in one wave tile
-    if (k.Cout <= 32) return launch_cfg<256, 32, 4, 1>(k, s);
-    if (k.Cout <= 64) return launch_cfg<128, 64, 2, 2>(k, s);
-    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return launch_cfg<128, 160, 4, 1>(k, s);
-    return launch_cfg<128, 128, 2, 2>(k, s);
+    if (pair) return urk::v1_128x128(&k, s);  // a|g 32-row blocks must sit in one wave tile
+    if (k.Cout <= 32) return urk::v1_256x32(&k, s);
+    if (k.Cout <= 64) return urk::v1_128x64(&k, s);
+    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return urk::v1_128x160(&k, s);
+    return urk::v1_128x128(&k, s);
   }
   // v2 (LDS-DMA ring).  One workgroup per CU: pick the 256-row / 8-wave tiles when they still fill the chip.
-  if (k.Cout <= 32) return launch_glds<256, 32, 4, 1, 3>(k, s, 200);
-  if (k.Cout <= 64 && !pair) return launch_glds<128, 64, 2, 2, 3>(k, s, 200);
+  if (k.Cout <= 32) return urk::v2_256x32(&k, s);
+  if (k.Cout <= 64 && !pair) return urk::v2_128x64(&k, s);
   const bool n160 = !pair && k.Cout % 160 == 0 && k.Cout % 128 != 0;
   const long long big_tiles = (long long)((k.M + 255) / 256) * ((k.Cout + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * k.nbatch;
   if (big_tiles >= 160) {
-    if (n160) return launch_glds<256, 160, 8, 1, 3>(k, s, 0);
-    return launch_glds<256, 128, 4, 2, 3>(k, s, 0);
+    if (n160) return urk::v2_256x160(&k, s);
+    return urk::v2_256x128(&k, s);
   }
-  static const int small_mode = getenv("UR_IGEMM_SMALL") ? atoi(getenv("UR_IGEMM_SMALL")) : 2;
-  if (small_mode == 1) return launch_glds<128, 128, 2, 2, 2>(k, s, 400);
-  if (small_mode == 2) {
-    if (k.Cout % 160 == 0 && k.Cout % 128 != 0 && !pair) return launch_cfg<128, 160, 4, 1>(k, s);
-    return launch_cfg<128, 128, 2, 2>(k, s);
-  }
-  return launch_glds<128, 128, 2, 2, 3>(k, s, 200);
+  // small problems: the register-staged kernel (two workgroups per CU), split-K when few tiles meet a long K
+  if (k.Cout % 160 == 0 && k.Cout % 128 != 0 && !pair) return urk::v1_128x160(&k, s);
+  return urk::v1_128x128(&k, s);
 }
 
 }  // namespace
