@@ -26,3 +26,19 @@ def test_ctypes_signatures_cover_header():
     assert sorted(capi.SIGNATURES) == _declared()
     assert capi.lib.ur_version() >= 100
     assert ctypes.sizeof(capi.ConvDesc) % 8 == 0
+
+
+def test_no_kernel_uses_scratch_memory():
+    """Accumulator arrays that end up in scratch (an un-unrolled loop makes their index dynamic) halve a kernel's speed
+    without failing any parity test: the build records every kernel's resource usage, this keeps scratch at zero."""
+    import json
+    import os
+    import unirestore_amd.build as b
+    b.build()
+    path = os.path.join(os.path.dirname(b.LIB), "build", "resource_usage.json")
+    if not os.path.exists(path):
+        b.build(force=True)
+    usage = json.load(open(path))
+    assert len(usage) >= 40
+    bad = {k: v["ScratchSize"] for k, v in usage.items() if v.get("ScratchSize", 0) > 0}
+    assert not bad, bad

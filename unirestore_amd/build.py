@@ -3,7 +3,9 @@
 The .so is written in-tree (unirestore_amd/libunirestore_hip.so) so it travels with a repo snapshot
 to the GPU box; it is git-ignored.  Rebuilds only when a source is newer than the library.
 """
+import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -41,14 +43,29 @@ def build(force=False, verbose=True):
 
     def one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        # per-kernel registers / scratch (a kernel whose accumulators land in scratch memory is 2x slower: keep it visible)
+        name = None
+        for line in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
+            if m and name:
+                usage.setdefault(f"{src}:{name}", {})[m.group(1).split(" ")[0]] = int(m.group(2))
         return obj
 
+    usage = {}
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(one, SOURCES))
+    with open(os.path.join(objdir, "resource_usage.json"), "w") as f:
+        json.dump(usage, f, indent=0, sort_keys=True)
+    spills = {k: v["ScratchSize"] for k, v in usage.items() if v.get("ScratchSize", 0) > 0}
+    if spills and verbose:
+        print(f"WARNING: kernels using scratch memory: {spills}", file=sys.stderr)
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

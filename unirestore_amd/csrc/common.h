@@ -31,9 +31,9 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 }
 
 // ------------------------------------------------------------------------------------------ math
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16 resolution): ~12 flops + one exp + one rcp
-// instead of libm's branchy erff (which cost ~50 us per 42 M GEGLU gates).
+// SiLU with the hardware reciprocal (1 ulp) instead of an IEEE division (~10 instructions)
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): kept for callers that need erf itself
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
@@ -44,7 +44,17 @@ __device__ __forceinline__ float erf_fast(float x) {
   const float r = 1.0f - poly * t * __expf(-ax * ax);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+// Exact (erf) GELU = x * Phi(x), with Phi(x) ~ sigmoid(a x + b x^3 + c x^5): minimax fit over [-8, 8] (argument clamped
+// there, Phi is saturated beyond), max |abs err| 2.5e-5 - two orders below bf16 resolution - in 7 full-rate instructions
+// + exp2 + rcp.  (The A-S erf above costs 16 + 2; the GEGLU epilogue of a 32768 x 2560 GEMM spent 22 us in it.)
+__device__ __forceinline__ float gelu_f(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float t = xc * xc;
+  // -log2(e) * (1.59501577, 7.40112920e-2, -7.03033577e-4)
+  float pz = fmaf(1.0142631e-3f, t, -0.10677573f);
+  pz = fmaf(pz, t, -2.3011214f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pz * xc));
+}
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {
     case UR_ACT_SILU: return silu_f(x);

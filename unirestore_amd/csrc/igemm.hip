@@ -136,6 +136,8 @@ static int conv_impl(const ur_conv_desc* d, ur_stream_t stream, int dry, int* pl
   k.dry = dry; k.plan_tn = 0; k.ln_parts = d->ln_parts;
   k.row_stats = d->row_stats; k.ln_stats = d->ln_stats; k.ln_colsum = d->ln_colsum; k.ln_eps = d->ln_eps; k.ln_dim = d->ln_dim;
   UR_REQUIRE(!d->ln_stats || (d->ln_colsum && d->ln_dim > 0), "ln_stats needs ln_colsum / ln_dim");
+  // feature combinations the specialised epilogues cover (each is one compiled instance; see epi_frag_pass)
+  UR_REQUIRE(!(d->bias_img_stride && (pair || d->ln_stats || d->yt)), "per-image bias rows do not combine with pair activations / LayerNorm folding / transposed columns");
   k.staged_ok_ = d->y && !d->out_f32 && !d->colsum && ((d->ldy | d->bs_y) & 7) == 0 &&
                  (!d->residual || ((d->ldr | d->bs_r) & 7) == 0);
   UR_REQUIRE(!d->gn_stats || (d->y && !d->out_f32 && !d->yt), "gn_stats needs a plain bf16 output");

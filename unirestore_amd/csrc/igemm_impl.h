@@ -338,9 +338,10 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
 #define UR_EPI_PASS(PAIR, LN, MULTI, YT, ACT) \
     epi_frag_pass<FM, FN, WTM, WTN, BM, BN, SROW, PAIR, LN, MULTI, YT, ACT>(p, acc, m0, n0, c0, wm, wn, lane, gb, smem, sbias, scol, srow)
     if (CLS == 0) { if (hasact) UR_EPI_PASS(0, 0, 0, 0, 1); else UR_EPI_PASS(0, 0, 0, 0, 0); }
-    else if (!pair && ln && !multi && !yt && !hasact) UR_EPI_PASS(0, 1, 0, 0, 0);
-    else if (pair && !multi && !yt) { if (ln) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0); }
-    else UR_EPI_PASS(2, 2, 2, 2, 2);
+    else if (pair) { if (ln) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0); }     // never with multi / yt (host-checked)
+    else if (yt) UR_EPI_PASS(0, 2, 0, 1, 2);                                                    // fused QKV with transposed V
+    else if (multi) UR_EPI_PASS(0, 0, 1, 0, 2);                                                 // per-image bias rows
+    else UR_EPI_PASS(0, 1, 0, 0, 2);                                                            // LayerNorm consumer
 #undef UR_EPI_PASS
   }
   if (p.dbg & 16) return;
@@ -397,7 +398,9 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
   else tile_copy<BM, BN, NT, SROW, false>(p, yb, p.ldy, smem, m0, p.M, c0, cmax);
 }
 
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT>
+// DIRECT_OK = false: the kernel is only ever launched with a staged-capable output (host-checked), so the unstaged
+// store path is not compiled in (its FN x FM x 4 unrolled stores are pure code-size ballast there).
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, bool DIRECT_OK = true>
 __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
                                                int gb, int sz, unsigned char* smem, bool owner = true) {
   // owner: this wave holds accumulator fragments (false for the loader waves of the warp-specialised kernel,
@@ -428,7 +431,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   const bool bias_geom_ok = !p.bias_img || p.patch_tw || (p.OHW % BM) == 0 || ((BM % p.OHW) == 0 && nimg_tile <= 4);
   const bool staged = p.staged_ok_ && BN >= 32 && bias_geom_ok;   // host-evaluated part: bf16 y, 16-byte aligned rows, no colsum
   if (!staged) {
-    if (owner) igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
+    if (DIRECT_OK && owner) igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
     return;
   }
   const bool plain = !pair && !p.ln_stats && nimg_tile == 1 && !p.yt;
@@ -1075,7 +1078,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, false>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
 }
 
 template <int BM, int BN, int WM, int WN, int NST>
@@ -1281,7 +1284,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     __builtin_amdgcn_s_barrier();
     if (++tap == 9) { tap = 0; ++c; }
   }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 }
 
 template <int TH, int BN, int WM, int WN>
@@ -1475,7 +1478,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
     __builtin_amdgcn_s_barrier();
     if (++tap == 9) { tap = 0; ++c; }
   }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 }
 
 template <int TH, int TW, int NIMG, int BN, int WM, int WN>
