@@ -1201,8 +1201,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
   const int cps = p.nk_per_split / 9, c_begin = sz * cps, nchunk = min(p.nk / 9, c_begin + cps) - c_begin;
   const int nk = nchunk * 9, kt0 = c_begin * 9;
 
-  auto issue_w = [&](int kt) {
-    unsigned char* st = wring + (kt % 3) * WBYTES;
+  auto issue_w = [&](int kt, int ring) {
+    unsigned char* st = wring + ring * WBYTES;
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
       const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
@@ -1232,57 +1232,59 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
   // ---- prologue: whole halo of chunk 0, weight tiles 0 and 1 ------------------------------------------------------------
 #pragma unroll
   for (int t = 0; t < HSLOTS; ++t) issue_h(0, t);
-  issue_w(0);
+  issue_w(0, 0);
   if (nk > 1) {
-    issue_w(1);
+    issue_w(1, 1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
 
-  for (int kt = 0, c = 0, tap = 0; kt < nk; ++kt) {
-    const bool more_w = kt + 2 < nk;
-    const bool more_h = tap < HSLOTS && c + 1 < nchunk;
-    if (more_w) issue_w(kt + 2);
-    if (more_h) {
+  // K loop as chunks x 9 UNROLLED taps: the tap decides everything that used to be run-time control in the loop body (which
+  // halo piece to prefetch, the fragment row offset, the weight-ring slot = tap % 3 because 9 % 3 == 0), so each tap's body
+  // is straight-line code with immediate LDS offsets instead of a branch ladder in front of every 20 MFMAs.
+  for (int c = 0; c < nchunk; ++c) {
+    const unsigned char* hb = hbuf + (c & 1) * HBYTES;
+    const bool next_chunk = c + 1 < nchunk;
 #pragma unroll
-      for (int t = 0; t < HSLOTS; ++t)                               // hpix[] must be indexed statically
-        if (tap == t) issue_h(c + 1, t);
-    }
-    // ---- MFMAs of K tile kt: B fragments = patch rows shifted by the tap, A fragments = weight tile -------------------
-    {
-      const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
-      const unsigned char* hb = hbuf + (c & 1) * HBYTES;
-      const unsigned char* wsm = wring + (kt % 3) * WBYTES;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kt = c * 9 + tap;
+      const bool more_w = kt + 2 < nk;
+      const bool more_h = tap < HSLOTS && next_chunk;
+      if (more_w) issue_w(kt + 2, (tap + 2) % 3);
+      if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
+      {
+        const int dy = tap / 3, dx = tap % 3;
+        const unsigned char* wsm = wring + (tap % 3) * WBYTES;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int slot = ks * 2 + fhalf;
-        bf16x8 bfr[FM], afr[FN];
+        for (int ks = 0; ks < 4; ++ks) {
+          const int slot = ks * 2 + fhalf;
+          bf16x8 bfr[FM], afr[FN];
 #pragma unroll
-        for (int b = 0; b < FM; ++b) {
-          const int hrow = (wm * FM + b + dy) * PW + dx + frow;
-          bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
+          for (int b = 0; b < FM; ++b) {
+            const int hrow = (wm * FM + b + dy) * PW + dx + frow;
+            bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
+          }
+#pragma unroll
+          for (int a = 0; a < FN; ++a) {
+            const int row = wn * WTN + a * 32 + frow;
+            afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+          }
+#pragma unroll
+          for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
         }
-#pragma unroll
-        for (int a = 0; a < FN; ++a) {
-          const int row = wn * WTN + a * 32 + frow;
-          afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int a = 0; a < FN; ++a)
-#pragma unroll
-          for (int b = 0; b < FM; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
       }
+      // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
+      if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
+      else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+      else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
-    // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
-    if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
-    else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-    else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (++tap == 9) { tap = 0; ++c; }
   }
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 }
@@ -1385,8 +1387,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
   const int c_begin = sz * cps, c_end = min(nchunk_all, c_begin + cps);
   const int nchunk = c_end - c_begin, nk = nchunk * 9, kt0 = c_begin * 9;
 
-  auto issue_w = [&](int kt) {
-    unsigned char* st = wring + (kt % 3) * WBYTES;
+  auto issue_w = [&](int kt, int ring) {
+    unsigned char* st = wring + ring * WBYTES;
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
       const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
@@ -1425,58 +1427,58 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
 
 #pragma unroll
   for (int t = 0; t < HSLOTS; ++t) issue_h(0, t);
-  issue_w(0);
+  issue_w(0, 0);
   if (nk > 1) {
-    issue_w(1);
+    issue_w(1, 1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
 
-  for (int kt = 0, c = 0, tap = 0; kt < nk; ++kt) {
-    const bool more_w = kt + 2 < nk;
-    const bool more_h = tap < HSLOTS && c + 1 < nchunk;
-    if (more_w) issue_w(kt + 2);
-    if (more_h) {
+  for (int c = 0; c < nchunk; ++c) {                       // chunks x 9 unrolled taps (see igemm_halo_kernel)
+    const unsigned char* hb = hbuf + (c & 1) * HBYTES;
+    const bool next_chunk = c + 1 < nchunk;
 #pragma unroll
-      for (int t = 0; t < HSLOTS; ++t)
-        if (tap == t) issue_h(c + 1, t);
-    }
-    {
-      const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
-      const unsigned char* hb = hbuf + (c & 1) * HBYTES;
-      const unsigned char* wsm = wring + (kt % 3) * WBYTES;
-      int hro[FM], hsw[FM];
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kt = c * 9 + tap;
+      const bool more_w = kt + 2 < nk;
+      const bool more_h = tap < HSLOTS && next_chunk;
+      if (more_w) issue_w(kt + 2, (tap + 2) % 3);
+      if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
+      {
+        const int dy = tap / 3, dx = tap % 3;
+        const unsigned char* wsm = wring + (tap % 3) * WBYTES;
+        int hro[FM], hsw[FM];
 #pragma unroll
-      for (int b = 0; b < FM; ++b) {
-        hro[b] = (hrow0[b] + dy * PW + dx) * 128;
-        hsw[b] = (((hin0[b] + dy * PW + dx) >> 1) - (hy0[b] + dy)) & 7;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int slot = ks * 2 + fhalf;
-        bf16x8 bfr[FM], afr[FN];
-#pragma unroll
-        for (int b = 0; b < FM; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hro[b] + ((slot ^ hsw[b]) << 4));
-#pragma unroll
-        for (int a = 0; a < FN; ++a) {
-          const int row = wn * WTN + a * 32 + frow;
-          afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        for (int b = 0; b < FM; ++b) {
+          hro[b] = (hrow0[b] + dy * PW + dx) * 128;
+          hsw[b] = (((hin0[b] + dy * PW + dx) >> 1) - (hy0[b] + dy)) & 7;
         }
 #pragma unroll
-        for (int a = 0; a < FN; ++a)
+        for (int ks = 0; ks < 4; ++ks) {
+          const int slot = ks * 2 + fhalf;
+          bf16x8 bfr[FM], afr[FN];
 #pragma unroll
-          for (int b = 0; b < FM; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < FM; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hro[b] + ((slot ^ hsw[b]) << 4));
+#pragma unroll
+          for (int a = 0; a < FN; ++a) {
+            const int row = wn * WTN + a * 32 + frow;
+            afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+          }
+#pragma unroll
+          for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
       }
+      if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
+      else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+      else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
-    if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
-    else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-    else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (++tap == 9) { tap = 0; ++c; }
   }
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 }
