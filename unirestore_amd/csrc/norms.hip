@@ -147,11 +147,21 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const uint16_t* __r
                                                              const double* __restrict__ pre1, const double* __restrict__ pre2,
                                                              int C1, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int HW, int C, int silu,
-                                                             int pix_per_block, int c_off, int C_total, int G, float eps, int CVS) {
+                                                             int pix_per_block, int c_off, int C_total, int G, float eps, int CVS, double inv_cnt) {
   __shared__ double gs[2][264];
   __shared__ float gm[2][264];
   const int n = blockIdx.y, t = threadIdx.x;
   const int CV = C >> 3, R = 256 / CVS, cpg = C_total / G;
+  // this thread's pixels / channel vector; the first batch of loads is issued BEFORE the statistics prologue (independent of it)
+  const int r = t / CVS, v = blockIdx.z * CVS + (t - r * CVS);
+  const bool worker = r < R && v < CV;
+  const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+  const uint16_t* xi = x + (long long)n * HW * C + (worker ? v : 0) * 8;
+  uint4 raw[4];
+  if (worker && p_begin + r < p_end) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)min(p_begin + r + u * R, p_end - 1) * C);
+  }
   const int cb = c_off + blockIdx.z * CVS * 8, ce = min(cb + CVS * 8, c_off + C);       // this slab in the C_total domain
   const int g_lo = cb / cpg, g_hi = (ce - 1) / cpg, ng = g_hi - g_lo + 1;
   for (int g = t; g < ng; g += 256) { gs[0][g] = 0.0; gs[1][g] = 0.0; }
@@ -164,15 +174,14 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const uint16_t* __r
   }
   __syncthreads();
   for (int g = t; g < ng; g += 256) {
-    const double cnt = (double)cpg * HW, mean = gs[0][g] / cnt;
-    double var = gs[1][g] / cnt - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
+    // mean / variance in fp64 (the subtraction cancels), 1/sqrt in fp32: inv_cnt comes from the host, so no fp64 divide / sqrt
+    const double mean = gs[0][g] * inv_cnt;
+    const double var = fma(gs[1][g], inv_cnt, -mean * mean);
     gm[0][g] = (float)mean;
-    gm[1][g] = (float)(1.0 / sqrt(var + (double)eps));
+    gm[1][g] = rsqrtf(fmaxf((float)var, 0.f) + eps);
   }
   __syncthreads();
-  const int r = t / CVS, v = blockIdx.z * CVS + (t - r * CVS);
-  if (r >= R || v >= CV) return;
+  if (!worker) return;
   float a[8], b[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -181,15 +190,14 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const uint16_t* __r
     a[e] = gm[1][g] * ga;
     b[e] = be - gm[0][g] * a[e];
   }
-  const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
-  const uint16_t* xi = x + (long long)n * HW * C + v * 8;
   uint16_t* yo = y + (long long)n * HW * C_total + c_off + v * 8;
   for (int p = p_begin + r; p < p_end; p += 4 * R) {        // 4 independent 16-byte loads in flight per thread
-    uint4 raw[4];
+    if (p != p_begin + r) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pp = min(p + u * R, p_end - 1);
-      raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)pp * C);
+      for (int u = 0; u < 4; ++u) {
+        const int pp = min(p + u * R, p_end - 1);
+        raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)pp * C);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -361,7 +369,7 @@ int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma
     for (int i = 0; i < 2; ++i)
       if (cs[i] > 0)
         hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], (uint16_t*)y, pre1,
-                           x2 ? pre2 : nullptr, C1, gamma, beta, HW, cs[i], silu, ppb[i], off[i], C, G, eps, cvs[i]);
+                           x2 ? pre2 : nullptr, C1, gamma, beta, HW, cs[i], silu, ppb[i], off[i], C, G, eps, cvs[i], 1.0 / ((double)cpg * HW));
     return ur::check_launch("ur_groupnorm_nhwc");
   }
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), (size_t)G * (2 * sizeof(double) + 2 * sizeof(float)), s, stats, ab,
