@@ -11,6 +11,9 @@
 //     XOR-swizzled LDS (2 stages, one barrier per tile); swizzles verified by tools/lds_conflicts.py.
 #include "common.h"
 
+// 128 B of zeros: source of out-of-range 16-byte pieces for the LDS-DMA loader
+static __device__ uint4 g_attn_zero_page[8];
+
 namespace {
 
 struct AttnP {
@@ -56,10 +59,37 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
     for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
   }
 
-  uint4 kr[KLD], vr[VLD];
-  auto load_tile = [&](int kv0) {
+  // K / V^T tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1-KiB piece = 8 rows x 128 B per wave
+  // instruction, landing lane-linearly), so the XOR swizzle lives on the SOURCE address: physical slot ps of row r gets
+  // logical chunk ps ^ f(r).  No staging registers, no ds_write_b128 (each costs ~13 LDS cycles next to the fragment reads).
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_attn_zero_page);
+  constexpr bool DMA = (D == 64);
+  const int lr = lane >> 3, ps = lane & 7;
+  uint4 kr[DMA ? 1 : KLD], vr[DMA ? 1 : VLD];
+  auto load_tile = [&](int kv0, int stage) {
+    if (DMA) {
+      unsigned char* ks = smem + stage * STAGE;
+      unsigned char* vs = ks + KT;
 #pragma unroll
-    for (int i = 0; i < KLD; ++i) {
+      for (int i = 0; i < 2; ++i) {                       // K: 8 pieces of 8 key rows; this wave issues pieces wid and wid + 4
+        const int piece = wid + 4 * i, row = piece * 8 + lr;
+        const int chunk = ps ^ ((row >> 1) & 7);
+        const uint16_t* g = kv0 + row < p.Tk ? K + (long long)(kv0 + row) * p.ldk + chunk * 8 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(ks + piece * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                       // V^T: 8 pieces of 8 channel rows x 64 keys
+        const int piece = wid + 4 * i, row = piece * 8 + lr;
+        const int chunk = ps ^ ((row >> 1) & 7);
+        const uint16_t* g = kv0 + chunk * 8 < p.ldvt ? V + (long long)row * p.ldvt + kv0 + chunk * 8 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(vs + piece * 1024), 16, 0, 0);
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < (DMA ? 0 : KLD); ++i) {
       const int idx = i * 256 + tid, row = idx / KSLOTS, slot = idx % KSLOTS;
       const bool ok = kv0 + row < p.Tk;
       const uint4* ptr = reinterpret_cast<const uint4*>(ok ? K + (long long)(kv0 + row) * p.ldk + slot * 8 : K);
@@ -67,7 +97,7 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
       kr[i] = ok ? v : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < VLD; ++i) {
+    for (int i = 0; i < (DMA ? 0 : VLD); ++i) {
       const int idx = i * 256 + tid, row = idx >> 3, slot = idx & 7;
       const bool ok = kv0 + slot * 8 < p.ldvt;   // padding columns [Tk, ldvt) are zero by contract
       const uint4* ptr = reinterpret_cast<const uint4*>(ok ? V + (long long)row * p.ldvt + kv0 + slot * 8 : V);
@@ -76,16 +106,17 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
     }
   };
   auto store_tile = [&](int stage) {
+    if (DMA) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }     // the DMA pieces of this stage have landed
     unsigned char* ks = smem + stage * STAGE;
     unsigned char* vs = ks + KT;
 #pragma unroll
-    for (int i = 0; i < KLD; ++i) {
+    for (int i = 0; i < (DMA ? 0 : KLD); ++i) {
       const int idx = i * 256 + tid, row = idx / KSLOTS, slot = idx % KSLOTS;
       const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
       *reinterpret_cast<uint4*>(ks + row * KROW + ((slot ^ sw) << 4)) = kr[i];
     }
 #pragma unroll
-    for (int i = 0; i < VLD; ++i) {
+    for (int i = 0; i < (DMA ? 0 : VLD); ++i) {
       const int idx = i * 256 + tid, row = idx >> 3, slot = idx & 7;
       *reinterpret_cast<uint4*>(vs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = vr[i];
     }
@@ -99,13 +130,13 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
   float m_run = -1e30f, l_run = 0.f;
 
   const int ntiles = (p.Tk + 63) / 64;
-  load_tile(0);
+  load_tile(0, 0);
   store_tile(0);
   __syncthreads();
   int stage = 0;
   for (int t = 0; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
-    if (more) load_tile((t + 1) * 64);
+    if (more) load_tile((t + 1) * 64, stage ^ 1);
     const unsigned char* ks = smem + stage * STAGE;
     const unsigned char* vs = ks + KT;
 
