@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libunirestore_hip.so")
-SOURCES = ["igemm_v1a.hip", "igemm_v1b.hip", "igemm_v2.hip", "igemm_halo.hip", "igemm.hip", "runtime.hip", "norms.hip",
+SOURCES = ["igemm_v1a.hip", "igemm_v1b.hip", "igemm_v2.hip", "igemm_halo.hip", "igemm_g1.hip", "igemm.hip", "runtime.hip", "norms.hip",
            "attention.hip", "elementwise.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-Wno-unused-result"]

@@ -25,6 +25,10 @@ int v2_128x64(void* kp, hipStream_t s);
 int v2_256x160(void* kp, hipStream_t s);
 int v2_256x128(void* kp, hipStream_t s);
 int gemm_256x256(void* kp, hipStream_t s);
+int g1_128x128(void* kp, hipStream_t s);
+int g1_128x160(void* kp, hipStream_t s);
+int g1_128x64(void* kp, hipStream_t s);
+int g1_64x64(void* kp, hipStream_t s);
 int halo_8x32_160(void* kp, hipStream_t s);
 int halo_8x32_128(void* kp, hipStream_t s);
 int himg_16x16(void* kp, hipStream_t s);
@@ -69,18 +73,23 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   const bool use_v1 = force_v1 || (k.KH == 1 && k.nk <= 10);
   const long long blocks128 = (long long)((k.M + 127) / 128) * ((k.Cout + 127) / 128) * k.nbatch;
   static const bool no_t64 = getenv("UR_IGEMM_NOT64") != nullptr;
+  // pure GEMMs that will not be split: the LDS-DMA twin of the register-staged kernel (no staging registers / ds_writes)
+  static const bool g1dma = getenv("UR_IGEMM_NOG1DMA") == nullptr;
+  const bool g1 = g1dma && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.pad_t == 0 && k.pad_l == 0 && k.OH == k.H && k.OW == k.W &&
+                  (long long)k.M * k.ldx + k.Ktot < (1ll << 31);
+  auto nosplit = [&](int bm, int bn) { return (long long)((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn) * k.nbatch >= 200 || k.nk < 8 || !k.ws; };
   if (!no_t64 && k.KH == 1 && !pair && k.Cout > 64) {
     // too few 128 x 128 tiles to fill 256 CUs and K too short for split-K to pay for its reduce pass: 64 x 64 tiles
-    if (blocks128 < 200 && k.nk <= 24) return urk::v1_64x64(&k, s);
+    if (blocks128 < 200 && k.nk <= 24) return g1 && nosplit(64, 64) ? urk::g1_64x64(&k, s) : urk::v1_64x64(&k, s);
     // 1 < tiles/CU < 2 at 128 x 128: halve the N tile so every CU gets the same work
-    if (use_v1 && blocks128 > 256 && blocks128 < 400 && k.Cout % 128 == 0) return urk::v1_128x64(&k, s);
+    if (use_v1 && blocks128 > 256 && blocks128 < 400 && k.Cout % 128 == 0) return g1 && nosplit(128, 64) ? urk::g1_128x64(&k, s) : urk::v1_128x64(&k, s);
   }
   if (use_v1) {
     if (pair) return urk::v1_128x128(&k, s);  // a|g 32-row blocks must sit in one wave tile
     if (k.Cout <= 32) return urk::v1_256x32(&k, s);
     if (k.Cout <= 64) return urk::v1_128x64(&k, s);
-    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return urk::v1_128x160(&k, s);
-    return urk::v1_128x128(&k, s);
+    if (k.Cout % 160 == 0 && k.Cout % 128 != 0) return g1 && nosplit(128, 160) ? urk::g1_128x160(&k, s) : urk::v1_128x160(&k, s);
+    return g1 && nosplit(128, 128) ? urk::g1_128x128(&k, s) : urk::v1_128x128(&k, s);
   }
   // v2 (LDS-DMA ring).  One workgroup per CU: pick the 256-row / 8-wave tiles when they still fill the chip.
   if (k.Cout <= 32) return urk::v2_256x32(&k, s);

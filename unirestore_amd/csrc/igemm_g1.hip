@@ -1,0 +1,9 @@
+// Instantiation unit: pure-GEMM LDS-DMA kernels at the small tile shapes (two-stage ring, two or more workgroups per CU).
+#include "igemm_impl.h"
+
+namespace urk {
+int g1_128x128(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 128, 2, 2, 2, true>(k, s); }
+int g1_128x160(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 160, 4, 1, 2, true>(k, s); }
+int g1_128x64(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 64, 2, 2, 2, true>(k, s); }
+int g1_64x64(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<64, 64, 2, 2, 2, true>(k, s); }
+}  // namespace urk

@@ -985,7 +985,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
 // offsets and nothing else is kept per row, which leaves room for 256 x 256 tiles (128 accumulator registers per wave).
 // Large-N GEMMs (GEGLU, fused QKV) are L2->CU ingest bound: at 128 x 128 tiles every flop costs 1/64 B of ingest,
 // at 256 x 256 half of that.
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, bool DIRECT = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
   constexpr int NT = WM * WN * 64, RPP = NT / 8;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
@@ -1078,10 +1078,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, false>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, DIRECT>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
 }
 
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, bool DIRECT = false>
 int launch_gemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.Cout + BN - 1) / BN;
@@ -1094,11 +1094,11 @@ int launch_gemm(ConvK& k, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k);
+  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k);
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
