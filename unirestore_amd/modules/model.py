@@ -106,6 +106,17 @@ class Controller(nn.Module):
         return {k: ops.nhwc_to_nchw(v) for k, v in out.items()}
 
 
+SIDE_STREAM = os.environ.get("UR_CSCE_STREAM", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
 class ControlledUNet(nn.Module):
     def __init__(self, unet: UNet2DConditionModel, control_type: str, null_embeds: Optional[torch.Tensor] = None,
                  cond_channels: int = 256):
@@ -153,15 +164,38 @@ class ControlledUNet(nn.Module):
             if blk.downsamplers is not None:
                 h = blk.downsamplers[0].run(h)
                 skips.append(h)
-        h = u.mid_block.run(h, step=step, ctx=ctx)
-        skips = [ed.run(s, control[s.shape[2]]) for ed, s in zip(self.csc_editors, skips)]      # SC-Tuner (base_model.py:233-238)
+        # SC-Tuner (base_model.py:233-238).  The adapters only need the skips and the control features, so they run on a side
+        # stream (a parallel branch of the captured graph) in the order the up path consumes them: the large 64x64-level
+        # adapter GEMMs overlap with the mid block / low-resolution up blocks, whose kernels leave most CUs idle.
+        raw, ready = skips, [None] * len(skips)
+        if SIDE_STREAM:
+            main, side = torch.cuda.current_stream(), _side_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            edited = [None] * len(raw)
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                for idx in reversed(range(len(raw))):
+                    edited[idx] = self.csc_editors[idx].run(raw[idx], control[raw[idx].shape[2]])
+                    ready[idx] = torch.cuda.Event()
+                    ready[idx].record(side)
+            h = u.mid_block.run(h, step=step, ctx=ctx)
+        else:
+            h = u.mid_block.run(h, step=step, ctx=ctx)
+            edited = [ed.run(s, control[s.shape[2]]) for ed, s in zip(self.csc_editors, raw)]
+        idx = len(raw)
         for blk in u.up_blocks:
             for i, res in enumerate(blk.resnets):
-                h = res.run(h, x2=skips.pop(), step=step)                                       # virtual torch.cat
+                idx -= 1
+                if ready[idx] is not None:
+                    torch.cuda.current_stream().wait_event(ready[idx])
+                h = res.run(h, x2=edited[idx], step=step)                                       # virtual torch.cat
                 if blk.attn_kind == "cross":
                     h = blk.attentions[i].run(h, ctx)
             if blk.upsamplers is not None:
                 h = blk.upsamplers[0].run(h)
+        # `raw` / `edited` stay referenced until here: memory handed out on one stream and read on the other must not be
+        # recycled while the other branch may still be using it
         h = u.conv_norm_out.run(h, silu=True)
         return ops.conv(h, u.conv_out.packed(), out_f32=True)
 

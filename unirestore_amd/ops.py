@@ -25,7 +25,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def workspace(dev, nbytes=192 << 20) -> torch.Tensor:
-    key = (dev, "splitk")
+    """Split-K partial planes.  One buffer per (device, stream): kernels on a side stream must not share it."""
+    key = (dev, "splitk", torch.cuda.current_stream().cuda_stream)
     if key not in _ws or _ws[key].numel() * 4 < nbytes:
         _ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     return _ws[key]
