@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from .. import ops, schedule
 from .adapters import CSCEAdapter, TaskFeatureAdapter, cfrm_blocks
+from . import nn as nnmod
 from .nn import (DEV, AutoencoderKL, Conv2d, DownBlock, MidBlock, ResnetBlock2D, TimestepEmbedding, UNet2DConditionModel,
                  invalidate_packed, sinusoid_table)
 
@@ -106,17 +107,6 @@ class Controller(nn.Module):
         return {k: ops.nhwc_to_nchw(v) for k, v in out.items()}
 
 
-SIDE_STREAM = os.environ.get("UR_CSCE_STREAM", "1") != "0"
-_SIDE = {}
-
-
-def _side_stream():
-    dev = torch.cuda.current_device()
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return _SIDE[dev]
-
-
 class ControlledUNet(nn.Module):
     def __init__(self, unet: UNet2DConditionModel, control_type: str, null_embeds: Optional[torch.Tensor] = None,
                  cond_channels: int = 256):
@@ -168,8 +158,8 @@ class ControlledUNet(nn.Module):
         # stream (a parallel branch of the captured graph) in the order the up path consumes them: the large 64x64-level
         # adapter GEMMs overlap with the mid block / low-resolution up blocks, whose kernels leave most CUs idle.
         raw, ready = skips, [None] * len(skips)
-        if SIDE_STREAM:
-            main, side = torch.cuda.current_stream(), _side_stream()
+        if nnmod.SIDE_STREAM:
+            main, side = torch.cuda.current_stream(), nnmod.side_stream()
             fork = torch.cuda.Event()
             fork.record(main)
             edited = [None] * len(raw)

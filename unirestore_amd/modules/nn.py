@@ -10,6 +10,8 @@ reference call sites are base_model.py:94-209, controller.py:101-170, autoencode
 import math
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,6 +19,16 @@ from .. import ops
 from ..ops import UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_SILU
 
 DEV = "cuda"
+SIDE_STREAM = os.environ.get("UR_CSCE_STREAM", "1") != "0"     # independent branches run as parallel branches of the graph
+_SIDE = {}
+
+
+def side_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
 FUSE_LN = __import__("os").environ.get("UR_FUSE_LN", "1") == "1"   # LayerNorm folded into the consuming GEMMs
 
 
@@ -143,7 +155,7 @@ class ResnetBlock2D(nn.Module):
                 bias = self.tbias[step]
         h = ops.conv(h, self.conv1.packed(), bias=bias, gn=True)
         h = self.norm2.run(h, silu=True)
-        if self.conv_shortcut is not None:
+        if self.conv_shortcut is not None:    # (tried as a parallel graph branch at the low-resolution levels: fork/join cost more than it hid)
             sc = ops.conv(x, self.conv_shortcut.packed(), x2=x2)
         else:
             sc = x
