@@ -1,4 +1,4 @@
-"""Small/medium GEMM shapes of the 16x16 / 8x8 / 32x32 levels, timed in a hipGraph; UR_IGEMM_SM selects experiment configs."""
+"""Small/medium GEMM shapes of the 16x16 / 8x8 / 32x32 levels, timed in a hipGraph (rows=1: producer of LayerNorm row sums)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
