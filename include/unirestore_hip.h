@@ -34,7 +34,8 @@ enum {
   UR_ACT_GELU = 2,  /* exact erf GELU (nn.GELU default) */
   UR_ACT_GEGLU = 3, /* out[j] = a[j] * gelu(g[j]); weight rows pre-interleaved in blocks of 32 (a|g) */
   UR_ACT_GATE = 4,  /* NAFNet SimpleGate: out[j] = a[j] * g[j]; same interleave */
-  UR_ACT_TANH = 5
+  UR_ACT_TANH = 5,
+  UR_ACT_RELU = 6   /* SPADE's mlp_shared (spade.py:47-49) */
 };
 
 int ur_version(void);
@@ -140,6 +141,9 @@ int ur_scale_channels(const void* x, const float* s, const void* residual, void*
                       ur_stream_t stream);
 /* y = a + b * s[c] (per-channel learnable residual scale beta/gamma, nafnet_arch.py:121,130) */
 int ur_axpy_channels(const void* a, const void* b, const float* s, void* y, long long rows, int C, ur_stream_t stream);
+/* SPADE modulation (spade.py:69): y = n * (1 + gamma) + beta (+ residual); gamma | beta = gb[:, 0:C] | gb[:, C:2C] (row stride ldgb) */
+int ur_spade_modulate(const void* n, const void* gb, int ldgb, const void* residual, void* y, long long rows, int C,
+                      ur_stream_t stream);
 /* tiny fp32 linear: y[m, g*Ng+n] = act(bias + sum_k x[m, g*Kg+k] * w[g*Ng+n, k]) (time MLPs, SCA, gates) */
 int ur_linear_f32(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int groups,
                   int act, ur_stream_t stream);

@@ -46,11 +46,14 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
-    def forward(self, x, temb=None):
+    def forward(self, x, temb=None, control=None):
+        """control: {width: feature map}; used only when a `spade` module was grafted on (base_model.py:56-92)."""
         h = self.conv1(F.silu(self.norm1(x)))
         if self.time_emb_proj is not None:
             h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
         h = self.conv2(F.silu(self.norm2(h)))
+        if control is not None and hasattr(self, "spade"):
+            h = self.spade(h, control[h.shape[-1]])          # base_model.py:85-86
         sc = x if self.conv_shortcut is None else self.conv_shortcut(x)
         return sc + h
 
@@ -226,10 +229,10 @@ class MidBlock(nn.Module):
         else:
             self.attentions = nn.ModuleList([AttentionBlock(c, head_dim, groups, eps)])
 
-    def forward(self, h, temb=None, ctx=None):
-        h = self.resnets[0](h, temb)
+    def forward(self, h, temb=None, ctx=None, control=None):
+        h = self.resnets[0](h, temb, control)
         h = self.attentions[0](h, ctx) if self.attn_kind == "cross" else self.attentions[0](h)
-        return self.resnets[1](h, temb)
+        return self.resnets[1](h, temb, control)
 
 
 class UpBlock(nn.Module):

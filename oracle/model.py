@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import schedule
-from .adapters import CSCEAdapter, TaskFeatureAdapter, cfrm_blocks
+from .adapters import SPADE, CSCEAdapter, TaskFeatureAdapter, cfrm_blocks
 from .blocks import (AutoencoderKL, DownBlock, MidBlock, ResnetBlock2D, TimestepEmbedding, UNet2DConditionModel,
                      gaussian_sample, sinusoidal_embedding)
 
@@ -62,7 +62,7 @@ class Controller(nn.Module):
 
 
 class ControlledUNet(nn.Module):
-    """/root/reference/src/modules/diffuie/base_model.py:13-245 (control_type == 'scedit')."""
+    """/root/reference/src/modules/diffuie/base_model.py:13-245 (control_type 'scedit' or 'spade')."""
 
     def __init__(self, unet: UNet2DConditionModel, control_type: str, null_embeds: Optional[torch.Tensor] = None,
                  cond_channels: int = 256):
@@ -70,14 +70,20 @@ class ControlledUNet(nn.Module):
         self.unet = unet
         cross_dim = unet.down_blocks[0].attentions[0].transformer_blocks[0].attn2.to_k.in_features
         self.register_buffer("null_embeds", null_embeds if null_embeds is not None else torch.zeros(1, 77, cross_dim))
-        if control_type != "scedit":
+        self.control_type = control_type
+        if control_type == "spade":                                  # base_model.py:32-37: a SPADE on every UNet resnet
+            for m in list(unet.modules()):
+                if isinstance(m, ResnetBlock2D):
+                    m.spade = SPADE(m.conv2.out_channels, cond_channels)
+        elif control_type == "scedit":
+            chans = [unet.conv_in.out_channels]
+            for blk in unet.down_blocks:
+                chans += [r.conv2.out_channels for r in blk.resnets]
+                if blk.downsamplers is not None:
+                    chans.append(chans[-1])
+            self.csc_editors = nn.ModuleList([CSCEAdapter(c, c, cond_channels) for c in chans])
+        else:
             raise ValueError(f"control_type '{control_type}' not supported")
-        chans = [unet.conv_in.out_channels]
-        for blk in unet.down_blocks:
-            chans += [r.conv2.out_channels for r in blk.resnets]
-            if blk.downsamplers is not None:
-                chans.append(chans[-1])
-        self.csc_editors = nn.ModuleList([CSCEAdapter(c, c, cond_channels) for c in chans])
 
     def forward(self, sample, control, timesteps):
         u = self.unet
@@ -85,20 +91,22 @@ class ControlledUNet(nn.Module):
         emb = u.time_embedding(sinusoidal_embedding(timesteps, u.time_proj_dim).to(sample.dtype))
         h = u.conv_in(sample)
         skips = [h]
+        sp = control if self.control_type == "spade" else None        # spade_resnet (base_model.py:56-92) vs _resnet (:47-54)
         for blk in u.down_blocks:
             for i, res in enumerate(blk.resnets):
-                h = res(h, emb)
+                h = res(h, emb, sp)
                 if blk.attn_kind == "cross":
                     h = blk.attentions[i](h, ctx)
                 skips.append(h)
             if blk.downsamplers is not None:
                 h = blk.downsamplers[0](h)
                 skips.append(h)
-        h = u.mid_block(h, emb, ctx)
-        skips = [ed(s, control[s.shape[-1]]) for ed, s in zip(self.csc_editors, skips)]
+        h = u.mid_block(h, emb, ctx, sp)
+        if hasattr(self, "csc_editors"):                              # base_model.py:233-238
+            skips = [ed(s, control[s.shape[-1]]) for ed, s in zip(self.csc_editors, skips)]
         for blk in u.up_blocks:
             for i, res in enumerate(blk.resnets):
-                h = res(torch.cat([h, skips.pop()], dim=1), emb)
+                h = res(torch.cat([h, skips.pop()], dim=1), emb, sp)
                 if blk.attn_kind == "cross":
                     h = blk.attentions[i](h, ctx)
             if blk.upsamplers is not None:

@@ -67,3 +67,24 @@ def test_lightning_prefix_slices_and_hf_folders(tmp_path):
     torch.save(torch.full(tuple(dst.base_model.null_embeds.shape), 0.5), tmp_path / "null_ok.pt")
     ck.load_null_embeds(dst, str(tmp_path / "null_ok.pt"))
     assert float(dst.base_model.null_embeds.mean()) == 0.5
+
+
+def test_spade_checkpoint_slices(tmp_path):
+    """control_type 'spade': controller + the SPADE modules inside base_model.unet come out of the cnet checkpoint."""
+    from unirestore_amd import checkpoint as ck
+    from unirestore_amd.modules import DiffUIE
+    kw = model_kwargs(1)
+    kw["cnet"]["type"] = "spade"
+    torch.manual_seed(1)
+    src = DiffUIE(**kw, **TINY); randomise_(src, 4)
+    torch.save({"state_dict": {"model." + k: v.clone() for k, v in src.state_dict().items()}}, tmp_path / "cnet.ckpt")
+    dst = DiffUIE(**kw, **TINY)
+    kw["cnet"]["ckpt_path"] = str(tmp_path / "cnet.ckpt")
+    ck.load_adapter_checkpoints(dst, cnet=kw["cnet"])
+    a, b = src.state_dict(), dst.state_dict()
+    n = 0
+    for k in a:
+        if ".spade." in k or k.startswith("controller."):
+            assert torch.equal(a[k], b[k]), k
+            n += 1
+    assert n > 100 and not hasattr(dst.base_model, "csc_editors")

@@ -152,3 +152,37 @@ def test_runner_validation_step_quantised(M):
     assert len(preds) == 1 and preds[0].shape == small.shape and 0.0 <= float(preds[0].min()) and float(preds[0].max()) <= 1.0
     with pytest.raises(ValueError):
         p(small, "ir", noise=(nz[0][..., :-1], nz[1]))
+
+
+def test_spade_golden(M):
+    """SPADE (spade.py:29-71) against the vector generated from the reference class."""
+    w, i, o = load_golden("spade_0")
+    m = M.SPADE(w["mlp_gamma.weight"].shape[0], w["mlp_shared.0.weight"].shape[1])
+    m.load_state_dict(w)
+    assert rel_l2(m(i["x"], i["segmap"]).cpu(), o["y"]) < 8e-3
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_spade_control_path(M, use_graph):
+    """control_type 'spade' (base_model.py:32-37,56-92): same parameter names as the oracle, UNet step and whole forward."""
+    from oracle.model import DiffUIE as ODiffUIE
+    kw = model_kwargs(2)
+    kw["cnet"]["type"] = "spade"
+    torch.manual_seed(3)
+    o = randomise_(ODiffUIE(**kw, **TINY).eval(), 3)
+    p = M.DiffUIE(**kw, **TINY, use_graph=use_graph).eval()
+    assert list(o.state_dict().keys()) == list(p.state_dict().keys())
+    assert sum("spade" in k for k in p.state_dict()) == 8 * sum(1 for _ in [m for m in o.base_model.unet.modules() if hasattr(m, "spade")])
+    p.load_state_dict(o.state_dict())
+    g = torch.Generator().manual_seed(9)
+    z0, zt, ts = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g), torch.tensor([499])
+    with torch.no_grad():
+        oc = o.controller(z0, ts)
+        oe = o.base_model(zt, oc, ts)
+    assert rel_l2(p.base_model(zt, oc, ts).cpu(), oe) < 2e-2
+    img = torch.rand(1, 3, 64, 64, generator=g)
+    noise = (torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g))
+    with torch.no_grad():
+        oy = o(img, "ir", noise=noise)
+    py = p(img, "ir", noise=noise)
+    assert py.shape == img.shape and rel_l2(py.cpu(), oy) < 3e-2

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunirestore_hip.so")
 
-UR_ACT_NONE, UR_ACT_SILU, UR_ACT_GELU, UR_ACT_GEGLU, UR_ACT_GATE, UR_ACT_TANH = range(6)
+UR_ACT_NONE, UR_ACT_SILU, UR_ACT_GELU, UR_ACT_GEGLU, UR_ACT_GATE, UR_ACT_TANH, UR_ACT_RELU = range(7)
 
 
 class ConvDesc(C.Structure):
@@ -52,6 +52,7 @@ SIGNATURES = {
     "ur_avgpool_hw": (_I, [_P, _P, _I, _I, _I, _P]),
     "ur_scale_channels": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ur_axpy_channels": (_I, [_P, _P, _P, _P, _LL, _I, _P]),
+    "ur_spade_modulate": (_I, [_P, _P, _I, _P, _P, _LL, _I, _P]),
     "ur_linear_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ur_tfa_prompt_update": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ur_vec_mul_group": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -47,8 +47,19 @@ def load_adapter_checkpoints(model, frenc: Optional[dict] = None, cnet: Optional
         state = _lightning_state(cnet["ckpt_path"])
         sd = slice_prefix(state, PREFIX_CONTROLLER)
         model.controller.load_state_dict(sd)
-        sd2 = slice_prefix(state, PREFIX_CSC)
-        model.base_model.csc_editors.load_state_dict(sd2)
+        if hasattr(model.base_model, "csc_editors"):
+            sd2 = slice_prefix(state, PREFIX_CSC)
+            model.base_model.csc_editors.load_state_dict(sd2)
+        else:
+            # control_type "spade": the trainable part of base_model are the SPADE modules grafted onto the UNet's resnets
+            # (engine_unifie.py:91-95 trains every module whose name contains "spade"; the reference's loader has no branch
+            # for them, so this follows the parameter names the training run would have saved)
+            sd2 = {k: v for k, v in slice_prefix(state, "model.base_model.").items() if ".spade." in k}
+            res = model.base_model.load_state_dict(sd2, strict=False)
+            want = {k for k in model.base_model.state_dict() if ".spade." in k}
+            if res.unexpected_keys or want - set(sd2):
+                raise RuntimeError(f"SPADE weights do not match: unexpected {list(res.unexpected_keys)[:4]} "
+                                   f"missing {sorted(want - set(sd2))[:4]}")
         loaded.append(("cnet", len(sd) + len(sd2)))
     if tedit and tedit.get("ckpt_path"):
         state = _lightning_state(tedit["ckpt_path"])

@@ -60,6 +60,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     case UR_ACT_SILU: return silu_f(x);
     case UR_ACT_GELU: return gelu_f(x);
     case UR_ACT_TANH: return tanhf(x);
+    case UR_ACT_RELU: return fmaxf(x, 0.f);
     default: return x;
   }
 }

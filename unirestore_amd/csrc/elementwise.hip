@@ -115,6 +115,24 @@ __global__ __launch_bounds__(256) void axpy_channels_kernel(const uint16_t* __re
   }
 }
 
+// SPADE modulation: y = n * (1 + gamma) + beta (+ residual), gamma | beta from one fused conv output [rows][2C]
+__global__ __launch_bounds__(256) void spade_modulate_kernel(const uint16_t* __restrict__ n, const uint16_t* __restrict__ gb, int ldgb,
+                                                             const uint16_t* __restrict__ res, uint16_t* __restrict__ y, int CV,
+                                                             long long totalv) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < totalv; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int v = (int)(i - r * CV);
+    float fn[8], fg[8], fb[8], fr[8];
+    unpack8(*reinterpret_cast<const uint4*>(n + i * 8), fn);
+    unpack8(*reinterpret_cast<const uint4*>(gb + r * ldgb + v * 8), fg);
+    unpack8(*reinterpret_cast<const uint4*>(gb + r * ldgb + (CV + v) * 8), fb);
+    if (res) unpack8(*reinterpret_cast<const uint4*>(res + i * 8), fr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fn[e] = fmaf(fn[e], 1.f + fg[e], fb[e]) + (res ? fr[e] : 0.f);
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8(fn);
+  }
+}
+
 // ---- tiny fp32 linear: one wave per output column, all M rows (M small) ------------------------------
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M, int N,
@@ -389,6 +407,17 @@ int ur_axpy_channels(const void* a, const void* b, const float* sc, void* y, lon
   hipLaunchKernelGGL(axpy_channels_kernel, dim3(nblocks(totalv)), dim3(256), 0, s, (const uint16_t*)a, (const uint16_t*)b, sc,
                      (uint16_t*)y, C / 8, totalv);
   return ur::check_launch("ur_axpy_channels");
+}
+
+int ur_spade_modulate(const void* n, const void* gb, int ldgb, const void* residual, void* y, long long rows, int C,
+                      ur_stream_t stream) {
+  UR_REQUIRE(n && gb && y && C % 8 == 0 && ldgb % 8 == 0 && ldgb >= 2 * C && rows > 0, "bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const long long totalv = rows * (C / 8);
+  ur::ProfScope prof("elementwise", 0.0, (residual ? 10.0 : 8.0) * totalv * 8.0, s);
+  hipLaunchKernelGGL(spade_modulate_kernel, dim3(nblocks(totalv)), dim3(256), 0, s, (const uint16_t*)n, (const uint16_t*)gb, ldgb,
+                     (const uint16_t*)residual, (uint16_t*)y, C / 8, totalv);
+  return ur::check_launch("ur_spade_modulate");
 }
 
 int ur_linear_f32(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int groups, int act,

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import UR_ACT_GATE, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_TANH
+from ..ops import UR_ACT_GATE, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_RELU, UR_ACT_TANH
 from .nn import DEV, Conv2d, LayerNorm, Linear, GroupNorm
 
 
@@ -41,6 +41,42 @@ class CSCEAdapter(nn.Module):
     def forward(self, x, condition):
         _fresh()
         return ops.nhwc_to_nchw(self.run(_to_nhwc(x), _to_nhwc(condition)), c=x.shape[1])
+
+
+class SPADE(nn.Module):
+    """Alternative control path (spade.py:29-71): out = GroupNorm(x) * (1 + gamma(seg)) + beta(seg), gamma / beta from a
+    shared conv3x3 + ReLU.  gamma and beta are ONE conv (weights concatenated); the modulation and the resnet's residual
+    add are one elementwise kernel."""
+
+    def __init__(self, norm_nc, label_nc=128, config_text="spadegroup3x3", nhidden=128):
+        super().__init__()
+        if config_text != "spadegroup3x3":
+            raise NotImplementedError(config_text)
+        self.param_free_norm = GroupNorm(32, norm_nc)          # affine despite the name (spade.py:40)
+        self.mlp_shared = _named(_0=Conv2d(label_nc, nhidden, 3, padding=1))
+        self.mlp_gamma = Conv2d(nhidden, norm_nc, 3, padding=1)
+        self.mlp_beta = Conv2d(nhidden, norm_nc, 3, padding=1)
+
+    def _gb(self):
+        if "gb" not in self.__dict__:
+            w = torch.cat([self.mlp_gamma.weight.detach().float(), self.mlp_beta.weight.detach().float()], 0)
+            b = torch.cat([self.mlp_gamma.bias.detach().float(), self.mlp_beta.bias.detach().float()], 0)
+            self.__dict__["gb"] = ops.pack_conv(w, b, DEV)
+        return self.__dict__["gb"]
+
+    def run(self, x, seg, residual=None):
+        """x [B,h,w,C] bf16 (with or without producer sums), seg [B,h2,w2,label_nc] -> modulated x (+ residual)."""
+        if seg.shape[1:3] != x.shape[1:3]:                      # F.interpolate(mode="nearest"): src = floor(dst * in / out)
+            iy = (torch.arange(x.shape[1], device=seg.device) * seg.shape[1]) // x.shape[1]
+            ix = (torch.arange(x.shape[2], device=seg.device) * seg.shape[2]) // x.shape[2]
+            seg = seg[:, iy][:, :, ix].contiguous()
+        actv = ops.conv(seg, self.mlp_shared["0"].packed(), act=UR_ACT_RELU)
+        gb = ops.conv(actv, self._gb())
+        return ops.spade_modulate(self.param_free_norm.run(x), gb, residual)
+
+    def forward(self, x, segmap):
+        _fresh()
+        return ops.nhwc_to_nchw(self.run(_to_nhwc(x), _to_nhwc(segmap)), c=x.shape[1])
 
 
 class LayerNorm2d(LayerNorm):

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops, schedule
-from .adapters import CSCEAdapter, TaskFeatureAdapter, cfrm_blocks
+from .adapters import SPADE, CSCEAdapter, TaskFeatureAdapter, cfrm_blocks
 from . import nn as nnmod
 from .nn import (DEV, AutoencoderKL, Conv2d, DownBlock, MidBlock, ResnetBlock2D, TimestepEmbedding, UNet2DConditionModel,
                  invalidate_packed, sinusoid_table)
@@ -118,16 +118,20 @@ class ControlledUNet(nn.Module):
             null_embeds = torch.load(p, map_location="cpu") if (cross_dim == 1024 and os.path.exists(p)) else \
                 torch.zeros(1, 77, cross_dim)
         self.register_buffer("null_embeds", null_embeds.float())
-        if control_type == "spade":
-            raise NotImplementedError("control_type 'spade' is not built yet (SURVEY.md §8f rank 3)")
-        if control_type != "scedit":
+        self.control_type = control_type
+        if control_type == "spade":                      # base_model.py:32-37: a SPADE on every ResnetBlock2D of the UNet
+            for m in list(unet.modules()):
+                if isinstance(m, ResnetBlock2D):
+                    m.spade = SPADE(m.conv2.out_channels, cond_channels)
+        elif control_type == "scedit":
+            chans = [unet.conv_in.out_channels]
+            for blk in unet.down_blocks:
+                chans += [r.conv2.out_channels for r in blk.resnets]
+                if blk.downsamplers is not None:
+                    chans.append(chans[-1])
+            self.csc_editors = nn.ModuleList([CSCEAdapter(c, c, cond_channels) for c in chans])
+        else:
             raise ValueError(f"control_type '{control_type}' not supported")
-        chans = [unet.conv_in.out_channels]
-        for blk in unet.down_blocks:
-            chans += [r.conv2.out_channels for r in blk.resnets]
-            if blk.downsamplers is not None:
-                chans.append(chans[-1])
-        self.csc_editors = nn.ModuleList([CSCEAdapter(c, c, cond_channels) for c in chans])
 
     def set_timesteps(self, timesteps):
         u = self.unet
@@ -145,9 +149,10 @@ class ControlledUNet(nn.Module):
         u, ctx = self.unet, self._ctx()
         h = ops.conv(zt_bf16, u.conv_in.packed(), gn=True)
         skips = [h]
+        sp = control if self.control_type == "spade" else None    # spade_resnet vs _resnet (base_model.py:47-92)
         for blk in u.down_blocks:
             for i, res in enumerate(blk.resnets):
-                h = res.run(h, step=step)
+                h = res.run(h, step=step, control=sp)
                 if blk.attn_kind == "cross":
                     h = blk.attentions[i].run(h, ctx)
                 skips.append(h)
@@ -158,7 +163,10 @@ class ControlledUNet(nn.Module):
         # stream (a parallel branch of the captured graph) in the order the up path consumes them: the large 64x64-level
         # adapter GEMMs overlap with the mid block / low-resolution up blocks, whose kernels leave most CUs idle.
         raw, ready = skips, [None] * len(skips)
-        if nnmod.SIDE_STREAM:
+        if sp is not None:                                  # SPADE control: no skip editors (base_model.py:233 hasattr check)
+            h = u.mid_block.run(h, step=step, ctx=ctx, control=sp)
+            edited = raw
+        elif nnmod.SIDE_STREAM:
             main, side = torch.cuda.current_stream(), nnmod.side_stream()
             fork = torch.cuda.Event()
             fork.record(main)
@@ -179,7 +187,7 @@ class ControlledUNet(nn.Module):
                 idx -= 1
                 if ready[idx] is not None:
                     torch.cuda.current_stream().wait_event(ready[idx])
-                h = res.run(h, x2=edited[idx], step=step)                                       # virtual torch.cat
+                h = res.run(h, x2=edited[idx], step=step, control=sp)                           # virtual torch.cat
                 if blk.attn_kind == "cross":
                     h = blk.attentions[i].run(h, ctx)
             if blk.upsamplers is not None:

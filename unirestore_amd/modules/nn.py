@@ -87,7 +87,7 @@ class LayerNorm(_NoEager, _Affine, nn.LayerNorm):
 def invalidate_packed(model: nn.Module):
     """Drop every cached device copy (call after loading new weights)."""
     for m in model.modules():
-        for k in [k for k in m.__dict__ if k in ("aff", "f32", "dw", "vecs", "fused", "ctx") or
+        for k in [k for k in m.__dict__ if k in ("aff", "f32", "dw", "vecs", "fused", "ctx", "gb") or
                   (isinstance(k, tuple) and k[0] in ("pk", "cache"))]:
             del m.__dict__[k]
 
@@ -141,9 +141,10 @@ class ResnetBlock2D(nn.Module):
             self.__dict__[key] = self.tbias.repeat_interleave(b, dim=0).contiguous()
         return self.__dict__[key]
 
-    def run(self, x, x2=None, step=None, sample_bias=None):
+    def run(self, x, x2=None, step=None, sample_bias=None, control=None):
         """x (+x2: virtual concat) NHWC bf16.  step: row of the time table, or "all" when the batch stacks every step of
-        the schedule (step-major); sample_bias: explicit [N,cout] per-image rows."""
+        the schedule (step-major); sample_bias: explicit [N,cout] per-image rows; control: {width: NHWC map} for a grafted
+        SPADE (base_model.py:56-92)."""
         h = self.norm1.run(x, silu=True, x2=x2)
         bias = None
         if self.time_emb_proj is not None:
@@ -159,6 +160,11 @@ class ResnetBlock2D(nn.Module):
             sc = ops.conv(x, self.conv_shortcut.packed(), x2=x2)
         else:
             sc = x
+        if control is not None and "spade" in self._modules:
+            if x2 is not None and self.conv_shortcut is None:
+                raise ValueError("identity shortcut cannot take a virtual concat")
+            h = ops.conv(h, self.conv2.packed(), gn=True)
+            return self.spade.run(h, control[h.shape[2]], residual=sc)          # (no fused sums: the next norm takes its own)
         return ops.conv(h, self.conv2.packed(), residual=sc, gn=True)
 
 
@@ -375,11 +381,11 @@ class MidBlock(nn.Module):
         else:
             self.attentions = nn.ModuleList([AttentionBlock(c, head_dim, groups, eps)])
 
-    def run(self, h, step=None, ctx=None, sample_bias=None):
+    def run(self, h, step=None, ctx=None, sample_bias=None, control=None):
         sb = sample_bias or (None, None)
-        h = self.resnets[0].run(h, step=step, sample_bias=sb[0])
+        h = self.resnets[0].run(h, step=step, sample_bias=sb[0], control=control)
         h = self.attentions[0].run(h, ctx) if self.attn_kind == "cross" else self.attentions[0].run(h)
-        return self.resnets[1].run(h, step=step, sample_bias=sb[1])
+        return self.resnets[1].run(h, step=step, sample_bias=sb[1], control=control)
 
 
 class UpBlock(nn.Module):

@@ -10,7 +10,8 @@ from typing import Optional
 import torch
 
 from . import capi
-from .capi import UR_ACT_GATE, UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_SILU, UR_ACT_TANH, ConvDesc, check, lib
+from .capi import (UR_ACT_GATE, UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_RELU, UR_ACT_SILU, UR_ACT_TANH, ConvDesc,
+                   check, lib)
 
 BF16 = torch.bfloat16
 _ws = {}
@@ -378,6 +379,14 @@ def scale_channels(x, s, residual=None):
     n, c = x.shape[0], x.shape[-1]
     out = torch.empty_like(x)
     check(lib.ur_scale_channels(x.data_ptr(), s.data_ptr(), _ptr(residual), out.data_ptr(), n, x.numel() // (n * c), c, _stream()))
+    return out
+
+
+def spade_modulate(n, gb, residual=None):
+    """y = n * (1 + gamma) + beta (+ residual); gb [..., 2C] = gamma | beta (spade.py:69)."""
+    c = n.shape[-1]
+    out = torch.empty_like(n)
+    check(lib.ur_spade_modulate(n.data_ptr(), gb.data_ptr(), gb.shape[-1], _ptr(residual), out.data_ptr(), n.numel() // c, c, _stream()))
     return out
 
 
