@@ -162,6 +162,14 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const uint16_t* __r
 #pragma unroll
     for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)min(p_begin + r + u * R, p_end - 1) * C);
   }
+  // affine parameters of this thread's 8 channels: also issued ahead of the prologue (one global round trip less on its tail)
+  float ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c_off + (worker ? v : 0) * 8 + e;
+    ga[e] = gamma ? gamma[c] : 1.f;
+    be[e] = beta ? beta[c] : 0.f;
+  }
   const int cb = c_off + blockIdx.z * CVS * 8, ce = min(cb + CVS * 8, c_off + C);       // this slab in the C_total domain
   const int g_lo = cb / cpg, g_hi = (ce - 1) / cpg, ng = g_hi - g_lo + 1;
   for (int g = t; g < ng; g += 256) { gs[0][g] = 0.0; gs[1][g] = 0.0; }
@@ -186,9 +194,8 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const uint16_t* __r
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = c_off + v * 8 + e, g = c / cpg - g_lo;
-    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    a[e] = gm[1][g] * ga;
-    b[e] = be - gm[0][g] * a[e];
+    a[e] = gm[1][g] * ga[e];
+    b[e] = be[e] - gm[0][g] * a[e];
   }
   uint16_t* yo = y + (long long)n * HW * C_total + c_off + v * 8;
   for (int p = p_begin + r; p < p_end; p += 4 * R) {        // 4 independent 16-byte loads in flight per thread
@@ -355,7 +362,10 @@ int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma
     const int R = 256 / cvs[i];
     // aim for >= ~2048 blocks (8 per CU) but keep >= 4 pixel rows per thread when the tensor is big enough
     long long want = std::max<long long>(1, 2048 / ((long long)N * slabs[i]));
-    chunks[i] = (int)std::min<long long>(want, std::max(1, HW / (8 * R)));
+    static const int ppt = getenv("UR_GN_PPT") ? atoi(getenv("UR_GN_PPT")) : 8;
+    static const int wantb = getenv("UR_GN_BLOCKS") ? atoi(getenv("UR_GN_BLOCKS")) : 2048;
+    want = std::max<long long>(1, wantb / ((long long)N * slabs[i]));
+    chunks[i] = (int)std::min<long long>(want, std::max(1, HW / (ppt * R)));
     ppb[i] = (HW + chunks[i] - 1) / chunks[i];
     chunks[i] = (HW + ppb[i] - 1) / ppb[i];
     const double* pre = i == 0 ? pre1 : pre2;
