@@ -20,14 +20,7 @@ from ..ops import UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_SILU
 
 DEV = "cuda"
 SIDE_STREAM = os.environ.get("UR_CSCE_STREAM", "1") != "0"     # independent branches run as parallel branches of the graph
-_SIDE = {}
-
-
-def side_stream():
-    dev = torch.cuda.current_device()
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return _SIDE[dev]
+side_stream = ops.side_stream
 
 FUSE_LN = __import__("os").environ.get("UR_FUSE_LN", "1") == "1"   # LayerNorm folded into the consuming GEMMs
 

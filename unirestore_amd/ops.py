@@ -25,9 +25,23 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_SIDE = {}
+
+
+def side_stream() -> "torch.cuda.Stream":
+    """The per-device side stream on which independent branches of a forward run (parallel branches of the captured graph)."""
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
 def workspace(dev, nbytes=192 << 20) -> torch.Tensor:
-    """Split-K partial planes.  One buffer per (device, stream): kernels on a side stream must not share it."""
-    key = (dev, "splitk", torch.cuda.current_stream().cuda_stream)
+    """Split-K partial planes: one buffer for the side stream, one for everything else (kernels of the main branch - whatever
+    stream or capture it runs under - are ordered among themselves; the side branch runs concurrently with them)."""
+    cur = torch.cuda.current_stream()
+    on_side = any(cur == s for s in _SIDE.values())
+    key = (dev, "splitk", on_side)
     if key not in _ws or _ws[key].numel() * 4 < nbytes:
         _ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     return _ws[key]
