@@ -426,6 +426,9 @@ class DiffUIE(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):    # an RCCL watchdog thread may be alive
                 outs = self._forward_device(static["images"], task, static["n_vae"], static["n_t"], plan, quantize)
+            max_graphs = int(os.environ.get("UR_MAX_GRAPHS", "8"))      # each captured shape keeps its own activation pool
+            while len(self._graphs) >= max(max_graphs, 1):
+                self._graphs.pop(next(iter(self._graphs)))                # oldest first
             g = self._graphs[key] = (graph, static, outs)
         graph, static, outs = g
         static["images"].copy_(images)
