@@ -42,3 +42,20 @@ def test_no_kernel_uses_scratch_memory():
     assert len(usage) >= 40
     bad = {k: v["ScratchSize"] for k, v in usage.items() if v.get("ScratchSize", 0) > 0}
     assert not bad, bad
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/unirestore_hip.h is the boundary a C / cgo / JNI caller would bind: it must compile as C99 on its own."""
+    import os
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "unirestore_hip.h"\nint main(void) { ur_conv_desc d; (void)d; return ur_version() > 0 ? 0 : 1; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
