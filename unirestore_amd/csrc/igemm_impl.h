@@ -711,17 +711,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const ConvK p) 
 // there is split-K, and each used to be followed by a separate statistics pass).  Block = 16 column quads x 16 row
 // lanes over 64 consecutive rows of ONE image (host guarantees OHW % 64 == 0); column sums stay in registers, the
 // row lanes meet in LDS, then one fp64 atomic per (column, moment) per block.
+template <int RI>   // rows per block = 16 * RI (one image: host checks OHW % (16 * RI) == 0)
 __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
   __shared__ float red[16][16][9];
   const int qc = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int q = blockIdx.x * 16 + qc, qn = p.Cout / 4, co = q * 4;
-  const int r0 = blockIdx.y * 64;
+  const int r0 = blockIdx.y * 16 * RI;
   float sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
   if (q < qn) {
-    float v[4][4];
-    uint2 rv[4];
+    float v[RI][4];
+    uint2 rv[RI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RI; ++i) {
       const int m = r0 + rl + 16 * i;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
     }
     const float g[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RI; ++i) {
       const int m = r0 + rl + 16 * i;
       epi_act(p, 0, m, co, v[i], g);
       v[i][0] += __uint_as_float(rv[i].x << 16); v[i][1] += __uint_as_float(rv[i].x & 0xffff0000u);
@@ -769,7 +770,12 @@ static void launch_splitk_reduce(ConvK& k, hipStream_t s) {
   if (k.row_stats || k.ln_stats) {
     hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(std::min((k.M + 3) / 4, 4096)), dim3(256), 0, s, k);
   } else if (!getenv("UR_IGEMM_NOGNRED") && k.gn_stats && !pair && k.staged_ok_ && k.nbatch == 1 && !k.yt && k.OHW % 64 == 0 && !k.patch_tw) {
-    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((k.Cout / 4 + 15) / 16, k.M / 64), dim3(256), 0, s, k);
+    // rows per block 64 / 32 / 16: the largest that still gives >= 512 workgroups (M = 512 at the 8x8 level needs the
+    // 16-row version: 160 workgroups of 64 rows left a third of the CUs idle in a latency-bound pass)
+    const long long colb = (k.Cout / 4 + 15) / 16;
+    if (colb * (k.M / 64) >= 512) hipLaunchKernelGGL(splitk_reduce_gn_kernel<4>, dim3(colb, k.M / 64), dim3(256), 0, s, k);
+    else if (colb * (k.M / 32) >= 512) hipLaunchKernelGGL(splitk_reduce_gn_kernel<2>, dim3(colb, k.M / 32), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL(splitk_reduce_gn_kernel<1>, dim3(colb, k.M / 16), dim3(256), 0, s, k);
     k.gn_fused = 1;
   } else {
     long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
