@@ -96,6 +96,16 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   if (k.Cout <= 64 && !pair) return urk::v2_128x64(&k, s);
   const bool n160 = !pair && k.Cout % 160 == 0 && k.Cout % 128 != 0;
   const long long big_tiles = (long long)((k.M + 255) / 256) * ((k.Cout + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * k.nbatch;
+  static const bool no_fill = getenv("UR_IGEMM_NOFILL") != nullptr;
+  if (!no_fill && g1 && !pair && big_tiles < 256) {
+    // 256-row tiles would leave CUs without a workgroup (e.g. 8192 x 640: 160 tiles): 128-row LDS-DMA tiles, two per CU,
+    // in the width that lands closest to whole CUs (8192 x 640 -> 64 x 4 tiles of 160 = 256)
+    const long long t160 = k.Cout % 160 == 0 ? (long long)((k.M + 127) / 128) * (k.Cout / 160) : 0;
+    const long long t128 = (long long)((k.M + 127) / 128) * ((k.Cout + 127) / 128);
+    auto fill = [](long long t) { return t <= 0 ? 0.0 : (double)t / (double)(((t + 255) / 256) * 256); };
+    if (t160 >= 200 && fill(t160) >= fill(t128)) return urk::g1_128x160(&k, s);
+    if (t128 >= 200) return urk::g1_128x128(&k, s);
+  }
   if (big_tiles >= 160) {
     if (n160) return urk::v2_256x160(&k, s);
     return urk::v2_256x128(&k, s);
