@@ -299,7 +299,8 @@ def test_conv_halo_tile_path(ops, n, cin, cout, h, w, ups, res):
     (256, 320, 960, False, 96), (300, 64, 128, False, 96), (512, 320, 2560, True, 96), (128, 640, 640, False, 96),
     (5200, 320, 2560, True, 96),             # >= 200 tiles of 256 x 256 -> gemm_glds_kernel
     (512, 1280, 1280, False, 1024),          # few tiles, long K: producer AND consumer go through split-K + the row-wise reduce
-    (200, 1280, 2560, True, 640), (2048, 1280, 1280, False, 96)])
+    (200, 1280, 2560, True, 640), (2048, 1280, 1280, False, 96),
+    (2048, 320, 10240, True, 96)])           # 256 x 320 gated tiles with the LayerNorm consumer
 def test_layernorm_fused_into_gemm(ops, rows, c, n, pair, k0):
     """Producer GEMM leaves per-row sums; the consumer computes Linear(LayerNorm(x)) without a LayerNorm pass."""
     g = _gen(rows + n)
@@ -321,7 +322,8 @@ def test_layernorm_fused_into_gemm(ops, rows, c, n, pair, k0):
     assert rel_l2(y.float().cpu(), ref) < 6e-3      # gamma is folded into bf16 weights: one extra bf16 rounding of W*gamma
 
 
-@pytest.mark.parametrize("m,k,n,act", [(5200, 320, 2560, "geglu"), (8192, 192, 1792, "gate")])
+@pytest.mark.parametrize("m,k,n,act", [(5200, 320, 2560, "geglu"), (8192, 192, 1792, "gate"),
+                                       (2048, 640, 10240, "geglu"), (2000, 320, 5120, "gate")])     # last two: 256 x 320 tiles
 def test_linear_pair_act_256_tiles(ops, m, k, n, act):
     """Large-N pair-activation GEMMs take the 256 x 256 pure-GEMM tile kernel (ragged M, K tail < 64)."""
     g = _gen(m + n)

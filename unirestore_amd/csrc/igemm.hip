@@ -25,6 +25,7 @@ int v2_128x64(void* kp, hipStream_t s);
 int v2_256x160(void* kp, hipStream_t s);
 int v2_256x128(void* kp, hipStream_t s);
 int gemm_256x256(void* kp, hipStream_t s);
+int gemm_256x320_pair(void* kp, hipStream_t s);
 int g1_128x128(void* kp, hipStream_t s);
 int g1_128x160(void* kp, hipStream_t s);
 int g1_128x64(void* kp, hipStream_t s);
@@ -67,7 +68,15 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   static const bool no_g256 = getenv("UR_IGEMM_NOG256") != nullptr;
   if (!no_g256 && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.staged_ok_ && k.Cout % 256 == 0 && !k.yt && (k.act == UR_ACT_GEGLU || k.act == UR_ACT_GATE) &&
       (long long)((k.M + 255) / 256) * (k.Cout / 256) * k.nbatch >= 200 && (long long)k.M * k.ldx < (1ll << 31))
+  {
+    // 320-wide tiles when they land on whole rounds of CUs (2048 x 10240: 8 x 32 = 256 tiles instead of 320)
+    static const bool no_g320 = getenv("UR_IGEMM_NOG320") != nullptr;
+    auto fill = [](long long t) { return (double)t / (double)(((t + 255) / 256) * 256); };
+    const long long tm = (k.M + 255) / 256;
+    if (!no_g320 && k.Cout % 320 == 0 && k.nbatch == 1 && !k.bias_img && fill(tm * (k.Cout / 320)) > fill(tm * (k.Cout / 256)))
+      return urk::gemm_256x320_pair(&k, s);
     return urk::gemm_256x256(&k, s);
+  }
   static const bool force_v1 = getenv("UR_IGEMM_V1") != nullptr;
   // short-K GEMMs (<= 10 K tiles: per-workgroup prologue/epilogue latency dominates): 128-row tiles, 2 workgroups per CU
   const bool use_v1 = force_v1 || (k.KH == 1 && k.nk <= 10);

@@ -288,10 +288,11 @@ __device__ __forceinline__ void epi_frag_pass(const ConvK& p, f32x16 (&acc)[FN][
 // Staged epilogue body.  CLS 0 = the plain class (no pair activation, no LayerNorm consumer, one bias row per tile, no
 // transposed columns): those features are compiled out, so the executed path is short and contiguous (skipping over
 // feature blocks costs an instruction-cache miss per far branch on a cold CU).  CLS 1 = everything, decided at run time.
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, int CLS>
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, int CLS, bool PAIRC = false>
 __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
                                                 int gb, unsigned char* smem, bool owner, int nimg_tile_in) {
-  constexpr int SROW = BN * 2 + 8;
+  // PAIRC: the kernel is only launched for pair activations (host-checked), whose output tile is BN/2 columns wide
+  constexpr int SROW = (PAIRC ? BN : BN * 2) + 8;
   const bool pair = CLS ? is_pair_act(p.act) : false;
   const bool ln = CLS ? p.ln_stats != nullptr : false;
   const bool yt = CLS ? p.yt != nullptr : false;
@@ -400,7 +401,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
 
 // DIRECT_OK = false: the kernel is only ever launched with a staged-capable output (host-checked), so the unstaged
 // store path is not compiled in (its FN x FM x 4 unrolled stores are pure code-size ballast there).
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, bool DIRECT_OK = true>
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, bool DIRECT_OK = true, bool PAIRC = false>
 __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
                                                int gb, int sz, unsigned char* smem, bool owner = true) {
   // owner: this wave holds accumulator fragments (false for the loader waves of the warp-specialised kernel,
@@ -435,7 +436,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
     return;
   }
   const bool plain = !pair && !p.ln_stats && nimg_tile == 1 && !p.yt;
-  if (plain) staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 0>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
+  if (PAIRC) { if (!plain) staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 1, true>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile); }
+  else if (plain) staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 0>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
   else staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 1>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
 }
 
@@ -991,7 +993,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
 // offsets and nothing else is kept per row, which leaves room for 256 x 256 tiles (128 accumulator registers per wave).
 // Large-N GEMMs (GEGLU, fused QKV) are L2->CU ingest bound: at 128 x 128 tiles every flop costs 1/64 B of ingest,
 // at 256 x 256 half of that.
-template <int BM, int BN, int WM, int WN, int NST, bool DIRECT = false>
+template <int BM, int BN, int WM, int WN, int NST, bool DIRECT = false, bool PAIRC = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
   constexpr int NT = WM * WN * 64, RPP = NT / 8;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
@@ -1084,10 +1086,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, DIRECT>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, DIRECT, PAIRC>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
 }
 
-template <int BM, int BN, int WM, int WN, int NST, bool DIRECT = false>
+template <int BM, int BN, int WM, int WN, int NST, bool DIRECT = false, bool PAIRC = false>
 int launch_gemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.Cout + BN - 1) / BN;
@@ -1095,16 +1097,16 @@ int launch_gemm(ConvK& k, hipStream_t s) {
   k.splitk = 1;
   k.nk_per_split = k.nk;
   k.gn_fused = k.gn_stats && k.staged_ok_ && (k.OHW % BM) == 0;
-  constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = BM * (BN * 2 + 8) + 7 * BN * 4 + BM * 8;
+  constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = BM * ((PAIRC ? BN : BN * 2) + 8) + 7 * BN * 4 + BM * 8;
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k);
+  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k);
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
