@@ -365,7 +365,8 @@ int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma
     static const int ppt = getenv("UR_GN_PPT") ? atoi(getenv("UR_GN_PPT")) : 8;
     static const int wantb = getenv("UR_GN_BLOCKS") ? atoi(getenv("UR_GN_BLOCKS")) : 2048;
     want = std::max<long long>(1, wantb / ((long long)N * slabs[i]));
-    chunks[i] = (int)std::min<long long>(want, std::max(1, HW / (ppt * R)));
+    // (8x8 maps: 2 pixel rows per thread - 40 workgroups of 8-deep loops were pure latency)
+    chunks[i] = (int)std::min<long long>(want, std::max(1, HW / ((HW <= 64 ? std::min(ppt, 2) : ppt) * R)));
     ppb[i] = (HW + chunks[i] - 1) / chunks[i];
     chunks[i] = (HW + ppb[i] - 1) / ppb[i];
     const double* pre = i == 0 ? pre1 : pre2;
