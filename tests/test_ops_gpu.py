@@ -385,3 +385,13 @@ def test_conv_whole_image_halo_tiles(ops, n, c1, c2, cout, hw, img_bias):
     st = ops.gn_of(y).view(n, cout, 2).cpu()
     yf = _nchw(y).double()
     assert rel_l2(st[..., 0], yf.sum((2, 3))) < 1e-5 and rel_l2(st[..., 1], (yf * yf).sum((2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("n,hw,c1,c2,cout", [(8, 64, 640, 320, 320), (8, 32, 1280, 640, 640), (2, 16, 1280, 1280, 1280)])
+def test_conv1x1_virtual_concat_shortcuts(ops, n, hw, c1, c2, cout):
+    """The up path's 1x1 shortcuts read cat[h, skip] without materialising it (pure-GEMM LDS-DMA kernel and fallbacks)."""
+    g = _gen(c1 + c2 + hw)
+    x = _rb(torch.randn(n, c1 + c2, hw, hw, generator=g)); wt = _rb(torch.randn(cout, c1 + c2, 1, 1, generator=g) / math.sqrt(c1 + c2))
+    b = torch.randn(cout, generator=g)
+    y = ops.conv(_nhwc(x[:, :c1]), ops.pack_conv(wt, b, "cuda"), x2=_nhwc(x[:, c1:]))
+    assert rel_l2(_nchw(y), F.conv2d(x, wt, b)) < TOL_BF16
