@@ -27,45 +27,25 @@ MFMA_PEAK_TFLOPS = 2500.0     # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.
 HBM_PEAK_GBS = 8000.0
 
 
-def init_random_(model, seed, device):
-    """Seeded random weights of the reference architecture (no checkpoints are reachable): N(0, 1/fan_in) weights,
-    unit norm gains, zero biases, small non-zero values for the reference's zero-initialised parameters."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            leaf = name.rsplit(".", 1)[-1]
-            if p.dim() >= 2 and leaf == "weight":
-                fan_in = p[0].numel()
-                p.copy_(torch.randn(p.shape, generator=g, device=device) * (0.7 / fan_in ** 0.5))
-            elif leaf == "weight":           # norm gains
-                p.fill_(1.0)
-            elif leaf == "bias":
-                p.zero_()
-            elif leaf in ("beta", "gamma"):
-                p.fill_(0.1)
-            else:                            # task prompts
-                p.copy_(torch.randn(p.shape, generator=g, device=device) * 0.02)
-        for name, b in model.named_buffers():
-            if name.endswith("null_embeds") and float(b.abs().sum()) == 0.0:
-                b.copy_(torch.randn(b.shape, generator=g, device=device))
+from unirestore_amd.init import init_random_  # noqa: E402,F401  (seeded random weights of the reference architecture)
 
 
-def build_model(denoise_steps, device, rank, world):
+def build_model(denoise_steps, device, rank, world, dtype="bf16"):
     import unirestore_amd.modules as M
     kw = dict(frenc=dict(type="CFRM"), cnet=dict(type="scedit", num_inference_steps=denoise_steps),
               tedit=dict(type="TFA", prompt_len=1, task=["ir", "cls", "seg"]))
     null = torch.load(os.path.join(ROOT, "unirestore_amd", "assets", "sd_null_emb.pt"), map_location="cpu")
     with torch.device("meta"):
-        model = M.DiffUIE(**kw, null_embeds=torch.empty(1, 77, 1024))
+        model = M.DiffUIE(**kw, null_embeds=torch.empty(1, 77, 1024), dtype=dtype)
     model = model.to_empty(device=device).eval()
     model.train_timesteps.copy_(torch.tensor([249, 499, 749, 999, 999, 999]))
     model.base_model.null_embeds.copy_(null)
     if rank == 0:
         init_random_(model, 42, device)
-    if world > 1:                            # RCCL broadcast of the weights from rank 0 (one flat bucket per ~256 MB)
+    if world > 1:                            # RCCL: rank 0's weights -> every rank as scatter + all-gather (every xGMI link busy)
         import torch.distributed as dist
         from unirestore_amd import dist as urdist
-        urdist.broadcast_weights(model, src=0)
+        urdist.broadcast_weights_sharded(model, src=0)
         dist.barrier()
     model.refresh()
     return model

@@ -7,8 +7,9 @@
  * through torch.nn / diffusers.  The "replaces" notes cite the reference call sites.
  *
  * Conventions
- *   - every pointer is a DEVICE address unless marked "host"; activations are NHWC bf16 (raw
- *     uint16 bit patterns), statistics / tables / tiny vectors are fp32;
+ *   - every pointer is a DEVICE address unless marked "host"; activations are NHWC 16-bit (raw uint16 bit
+ *     patterns of bf16 or fp16, chosen per call by a UR_DT_* `dtype`), statistics / tables / tiny vectors are fp32;
+ *   - no kernel uses atomics: two runs (or two hipGraph replays) on the same inputs are bit-identical;
  *   - the library never allocates: workspaces are passed in by the caller;
  *   - every call is asynchronous on `stream` (a hipStream_t) and safe under hipGraph capture;
  *   - return value: 0 = UR_OK, negative = UR_E_*; ur_last_error() gives the message (thread-local).
@@ -26,6 +27,12 @@ extern "C" {
 typedef void* ur_stream_t; /* hipStream_t */
 
 enum { UR_OK = 0, UR_E_INVALID = -1, UR_E_UNSUPPORTED = -2, UR_E_LAUNCH = -3, UR_E_WORKSPACE = -4 };
+
+/* 16-bit storage / matrix-core operand type of activations and weights (accumulation, statistics, softmax, the DDIM state
+ * and every tiny vector are fp32 in both).  UR_DT_BF16: precision: bf16-mixed of the reference (configs/val.yaml:12);
+ * UR_DT_F16: IEEE half - same bytes and MFMA rate, 8x smaller rounding error per stored tensor, conversions saturate at
+ * +-65504 (BASELINE.json configs[4], "fp16"). */
+enum { UR_DT_BF16 = 0, UR_DT_F16 = 1 };
 
 /* epilogue activations */
 enum {
@@ -58,12 +65,17 @@ typedef struct ur_conv_desc {
   const void* w;        /* bf16 [Cout][KH*KW*(C1+C2)] row stride ldw */
   const float* bias;    /* fp32 [Cout] or NULL */
   const void* residual; /* bf16 [M, ldr] or NULL (M = N*OH*OW) */
-  void* y;              /* bf16 (or fp32 if out_f32) [M, ldy]; may be NULL if only colsum is wanted */
+  void* y;              /* 16-bit (or fp32 if out_f32) [M, ldy]; may be NULL if only gn_part is wanted */
   void* yt;             /* bf16 transposed output for columns >= n_split: [M/t_rows][Cout-n_split][t_ld] or NULL */
-  float* colsum;        /* fp32 [N][nbatch*Cout_out] += colsum_scale * sum over the image's rows (atomic; fused
-                           AdaptiveAvgPool2d(1), taskeditor.py:35) or NULL; batch index = channel group */
-  double* gn_stats;     /* fp64 [N][nbatch*Cout_out][2] += (sum, sum of squares) of the stored bf16 outputs per image and
-                           channel (atomic; statistics for the GroupNorm that consumes y) or NULL */
+  float* gn_part;       /* fp32 [N][P][nbatch*Cout_out][2] = partial (sum, sum of squares) of the 16-bit outputs per image,
+                           row chunk and channel, plain stores (P = ur_conv_plan.gn_parts): statistics for the GroupNorm /
+                           InstanceNorm / AdaptiveAvgPool2d(1) that consumes y (ur_groupnorm_finalize), or NULL.  With
+                           ur_conv_plan.gn_fused the epilogue writes them and y may be NULL (pooled output only:
+                           taskeditor.py:35); otherwise one extra pass over y does */
+  const float* gn_ab;   /* fp32 [N][2][C1+C2] per-(image, input channel) affine (a | b) from ur_groupnorm_finalize, or NULL:
+                           the conv reads act(a*x + b) instead of x (GroupNorm apply [+ SiLU] of ResnetBlock2D fused into the
+                           conv's loader; zero padding stays zero).  Only where ur_conv_plan.prologue_ok */
+  int gn_silu;          /* 1: SiLU after the gn_ab affine */
   float* row_stats;     /* fp32 [parts][M][2] = per-row (sum, sum of squares) of this GEMM's output, one partial plane per N
                            tile (plain stores; parts = ur_conv2d_row_stat_parts(desc)): the LayerNorm statistics of the
                            GEMM that consumes y (BasicTransformerBlock norm1-3) or NULL */
@@ -85,40 +97,71 @@ typedef struct ur_conv_desc {
   int out_f32;
   int n_split, t_rows, t_ld;
   float out_scale;      /* applied after act; 1.0 for none */
-  float colsum_scale;
   int nbatch;           /* >= 1 */
   long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r; /* element strides per batch index */
   int k_chunk_major;    /* 1: weight K index runs (64-channel chunk, tap, channel) instead of (tap, channel): the taps of
                            one chunk are consecutive K tiles, so re-reads of a pixel hit L2 (needs C1, C1+C2 % 64 == 0) */
   long long bias_img_stride; /* 0: one bias row; else bias row of image n = m/(OH*OW) is bias + n*stride
                                 (per-sample time embeddings, unifie.py:91-105) */
+  int dtype;            /* UR_DT_BF16 | UR_DT_F16: type of x, x2, w, residual, y (unless out_f32), yt */
 } ur_conv_desc;
 
 int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream);
-/* host-only query: how many partial row-sum planes the launch of `d` writes into d->row_stats */
-int ur_conv2d_row_stat_parts(const ur_conv_desc* d);
+
+/* host-only query (no launch): what the launch of `d` will do.  Fill d exactly as for the real call (non-NULL dummies
+ * are fine for row_stats / gn_part / gn_ab when only the plan is wanted). */
+typedef struct ur_conv_plan {
+  int row_stat_parts; /* partial planes the launch writes into d->row_stats */
+  int gn_parts;       /* partials per image (P) the launch writes into d->gn_part */
+  int gn_fused;       /* 1: written by the conv epilogue itself (y may be NULL); 0: by an extra pass over y */
+  int prologue_ok;    /* 1: d->gn_ab is honoured inside this launch; 0: apply the GroupNorm separately */
+} ur_conv_plan;
+int ur_conv2d_plan(const ur_conv_desc* d, ur_conv_plan* plan);
+
+/* Linear / 1x1 convolution with the epilogues of SURVEY.md 8(b): y[m, n] = act(x[m, :] . w[n, :] + bias[n]) (+ residual);
+ * act in UR_ACT_* (GEGLU / GATE: w rows pre-interleaved, N = 2 * output columns).  Thin wrapper over ur_conv2d_nhwc. */
+int ur_gemm_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y, long long M, int N, int K,
+                     int ldx, int ldw, int ldy, int ldr, int act, float* workspace, size_t workspace_bytes, int dtype,
+                     ur_stream_t stream);
+/* grouped 3x3 convolution (pad 1, stride 1) + activation: AdaNAFV2.group_conv (cfrm.py:20-21), the three TFA gate branches
+ * (taskeditor.py:30-52).  x [N,H,W,G*Cg], w [G*Cog][9*Cg], y [N,H,W,G*Cog].  Thin wrapper over ur_conv2d_nhwc (nbatch = G). */
+int ur_groupconv3x3_nhwc(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cg, int Cog,
+                         int groups, int act, float* workspace, size_t workspace_bytes, int dtype, ur_stream_t stream);
 
 /* ---- normalisation (HBM-bound) ----------------------------------------------------------------
- * GroupNorm over NHWC (+ optional SiLU).  G == C with gamma=beta=NULL gives InstanceNorm2d.
+ * GroupNorm over NHWC (+ optional SiLU) in three steps, all without atomics:
+ *   1. statistics: fp32 partial planes part[N][P][C][2] (sum, sum of squares per image, pixel chunk, channel) - written by the
+ *      PRODUCER's epilogue (ur_conv_desc.gn_part) or by ur_groupnorm_stats;
+ *   2. ur_groupnorm_finalize: partials of one or two (virtually concatenated) sources -> fp32 ab[N][2][C] with
+ *      y = a*x + b == GroupNorm(x); fp64 sums in a fixed order;
+ *   3. ur_groupnorm_apply_act (or ur_conv_desc.gn_ab: applied inside the consuming convolution).
+ * G == C with gamma = beta = NULL gives InstanceNorm2d; mean_out gives AdaptiveAvgPool2d(1).
  * Replaces: nn.GroupNorm(32,C)+SiLU in every ResnetBlock2D / conv_norm_out, Transformer2D / Attention
- *   pre-norms, AdaNAFV2.group_norm (cfrm.py:19), nn.InstanceNorm2d (taskeditor.py:31,40,49).
- * ws: scratch of ur_groupnorm_ws_bytes(N, C) bytes that must be ZERO on first use (it is left zero by every call).
+ *   pre-norms, AdaNAFV2.group_norm (cfrm.py:19), nn.InstanceNorm2d (taskeditor.py:31,40,49), nn.AdaptiveAvgPool2d(1).
  */
-size_t ur_groupnorm_ws_bytes(int N, int C); /* fp64 channel sums: zero on first use, left zero by every call */
-size_t ur_groupnorm_ab_bytes(int N, int C); /* fp32 per-(image, channel) affine table: plain scratch */
-/* x2/C2 (optional): second source tensor, virtually concatenated after x's C1 channels (UNet up path:
- * GroupNorm over torch.cat([sample, skip]), base_model.py:189,197); y is [N,HW,C1+C2]. */
-/* pre1 / pre2 (optional): channel sums of x / x2 already produced by ur_conv_desc.gn_stats ([N][C1][2] / [N][C2][2]);
- * when given, the statistics pass over that tensor is skipped (they are read, not cleared). */
+int ur_groupnorm_stats_parts(int N, int HW, int C);   /* host: P of the plane ur_groupnorm_stats writes */
+size_t ur_groupnorm_ws_bytes(int N, int HW, int C);   /* bytes of that plane */
+size_t ur_groupnorm_ab_bytes(int N, int C);           /* bytes of an ab table */
+int ur_groupnorm_stats(const void* x, float* part, int N, int HW, int C, int dtype, ur_stream_t stream);
+int ur_instnorm_stats(const void* x, float* part, int N, int HW, int C, int dtype, ur_stream_t stream); /* same pass */
+/* part2/parts2/C2 (optional): second source, virtually concatenated after part1's C1 channels (UNet up path: GroupNorm over
+ * torch.cat([sample, skip]), base_model.py:189,197).  ab and/or mean_out ([N][G] group means) may be NULL. */
+int ur_groupnorm_finalize(const float* part1, int parts1, int C1, const float* part2, int parts2, int C2, const float* gamma,
+                          const float* beta, int N, int HW, int G, float eps, float* ab, float* mean_out, ur_stream_t stream);
+/* y[N,HW,C1+C2] = act(a*x + b) over x [N,HW,C1] (| x2 [N,HW,C2]) */
+int ur_groupnorm_apply_act(const void* x, const void* x2, void* y, const float* ab, int N, int HW, int C1, int C2, int silu,
+                           int dtype, ur_stream_t stream);
+/* the three chained.  pre1 / pre2 (optional): producer-side partial planes of x / x2 with parts1 / parts2 partials per image;
+ * ws: ur_groupnorm_ws_bytes(N,HW,C1) [+ (N,HW,C2)] bytes of scratch, needed only for sources without producer partials */
 int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int N, int HW,
-                      int C1, int C2, int G, float eps, int silu, void* ws, float* ab, const double* pre1,
-                      const double* pre2, ur_stream_t stream);
-/* LayerNorm over the last dim of [rows, C] bf16 (nn.LayerNorm in BasicTransformerBlock; timm LayerNorm2d
+                      int C1, int C2, int G, float eps, int silu, float* ws, float* ab, const float* pre1, int parts1,
+                      const float* pre2, int parts2, int dtype, ur_stream_t stream);
+/* LayerNorm over the last dim of [rows, C] (nn.LayerNorm in BasicTransformerBlock; timm LayerNorm2d
  * in NAFBlock, nafnet_arch.py:97-98, which is LayerNorm-over-C in NHWC). */
 int ur_layernorm_rows(const void* x, void* y, const float* gamma, const float* beta, long long rows, int C,
-                      float eps, ur_stream_t stream);
-/* softmax over rows of an fp32 [rows, cols] matrix -> bf16 (VAE mid-block attention, upcast_softmax). */
-int ur_softmax_rows_f32(const float* s, void* p, long long rows, int cols, int ldp, ur_stream_t stream);
+                      float eps, int dtype, ur_stream_t stream);
+/* softmax over rows of an fp32 [rows, cols] matrix -> 16-bit (upcast_softmax). */
+int ur_softmax_rows_f32(const float* s, void* p, long long rows, int cols, int ldp, int dtype, ur_stream_t stream);
 
 /* ---- attention (flash-style, bf16 MFMA, fp32 softmax) ------------------------------------------
  * o[b,t,h*D+d] = softmax_k(q.k * scale) v.  q:[B][Tq][ldq], k:[B][Tk][ldk] (head h at column h*D),
@@ -128,22 +171,22 @@ int ur_softmax_rows_f32(const float* s, void* p, long long rows, int cols, int l
  */
 int ur_attention_fwd(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk,
                      int D, int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k,
-                     long long bs_vt, long long bs_o, float scale, ur_stream_t stream);
+                     long long bs_vt, long long bs_o, float scale, int dtype, ur_stream_t stream);
 
 /* ---- HBM-bound stencils / reductions / elementwise ---------------------------------------------*/
 /* depthwise 3x3 (pad 1) + bias, optional SimpleGate (out channels C/2): nafnet_arch.py:41-49,22-25 */
 int ur_dwconv3x3_nhwc(const void* x, const float* w9c, const float* bias, void* y, int N, int H, int W, int C,
-                      int gate, ur_stream_t stream);
-/* mean over HW -> fp32 [N][C] (nn.AdaptiveAvgPool2d(1)) */
-int ur_avgpool_hw(const void* x, float* out, int N, int HW, int C, ur_stream_t stream);
+                      int gate, int dtype, ur_stream_t stream);
+/* mean over HW -> fp32 [N][C] (nn.AdaptiveAvgPool2d(1)): statistics pass + finalize; ws = ur_groupnorm_ws_bytes(N,HW,C) bytes */
+int ur_avgpool_hw(const void* x, float* out, int N, int HW, int C, float* ws, int dtype, ur_stream_t stream);
 /* y = x * s[n][c] (+ residual) : channel attention scaling (nafnet_arch.py:116, cfrm.py:46-48, taskeditor.py:95) */
 int ur_scale_channels(const void* x, const float* s, const void* residual, void* y, int N, int HW, int C,
-                      ur_stream_t stream);
+                      int dtype, ur_stream_t stream);
 /* y = a + b * s[c] (per-channel learnable residual scale beta/gamma, nafnet_arch.py:121,130) */
-int ur_axpy_channels(const void* a, const void* b, const float* s, void* y, long long rows, int C, ur_stream_t stream);
+int ur_axpy_channels(const void* a, const void* b, const float* s, void* y, long long rows, int C, int dtype, ur_stream_t stream);
 /* SPADE modulation (spade.py:69): y = n * (1 + gamma) + beta (+ residual); gamma | beta = gb[:, 0:C] | gb[:, C:2C] (row stride ldgb) */
 int ur_spade_modulate(const void* n, const void* gb, int ldgb, const void* residual, void* y, long long rows, int C,
-                      ur_stream_t stream);
+                      int dtype, ur_stream_t stream);
 /* tiny fp32 linear: y[m, g*Ng+n] = act(bias + sum_k x[m, g*Kg+k] * w[g*Ng+n, k]) (time MLPs, SCA, gates) */
 int ur_linear_f32(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int groups,
                   int act, ur_stream_t stream);
@@ -153,34 +196,34 @@ int ur_tfa_prompt_update(const float* pooled, const float* cond, float* upd, int
 int ur_vec_mul_group(const float* a, const float* b, float* out, int N, int C, int G, ur_stream_t stream);
 
 /* ---- latent / image boundary --------------------------------------------------------------------*/
-/* images NCHW fp32 in [0,1] -> NHWC bf16 (x*2-1), channels padded with zeros to Cpad (autoencoder.py:149) */
-int ur_image_to_nhwc(const float* img, void* y, int N, int C, int H, int W, int Cpad, ur_stream_t stream);
-/* NHWC fp32/bf16 [N,H,W,ld] first C channels -> NCHW fp32, out = x*mul+add (autoencoder.py:175) */
+/* images NCHW fp32 in [0,1] -> NHWC 16-bit (x*2-1), channels padded with zeros to Cpad (autoencoder.py:149) */
+int ur_image_to_nhwc(const float* img, void* y, int N, int C, int H, int W, int Cpad, int dtype, ur_stream_t stream);
+/* NHWC fp32/16-bit [N,H,W,ld] first C channels -> NCHW fp32, out = x*mul+add (autoencoder.py:175) */
 int ur_nhwc_to_nchw_f32(const void* x, int x_is_f32, float* out, int N, int C, int H, int W, int ld, float mul,
-                        float add, ur_stream_t stream);
-/* NCHW fp32 -> NHWC bf16 with channel padding (module-level API plumbing) */
-int ur_nchw_f32_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, ur_stream_t stream);
+                        float add, int dtype, ur_stream_t stream);
+/* NCHW fp32 -> NHWC 16-bit with channel padding (module-level API plumbing) */
+int ur_nchw_f32_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype, ur_stream_t stream);
 /* DiffUIE.forward pre-processing (reference unifie.py:124-134) fused with the encoder's x*2-1 (autoencoder.py:152 -> vae.encode)
  * and the NHWC layout pass: img fp32 [N,C,H,W] -> F.interpolate(bicubic, align_corners=False, antialias=False) to RH x RW
- * (skipped when equal) -> F.pad(reflect) right/bottom by PW/PH -> v*mul+add -> y bf16 [N,RH+PH,RW+PW,Cpad]. */
+ * (skipped when equal) -> F.pad(reflect) right/bottom by PW/PH -> v*mul+add -> y 16-bit [N,RH+PH,RW+PW,Cpad]. */
 int ur_image_resize_pad_nhwc(const float* img, void* y, int N, int C, int H, int W, int RH, int RW, int PH, int PW, int Cpad,
-                             float mul, float add, ur_stream_t stream);
+                             float mul, float add, int dtype, ur_stream_t stream);
 /* DiffUIE.forward post-processing (unifie.py:164-168) and the evaluator's 8-bit quantisation (eval_image_restoration.py:71):
- * x NHWC (bf16 | fp32) [N,XH,XW,ld] -> v*mul+add -> crop [0:CH,0:CW] -> bicubic to OH x OW -> optional
+ * x NHWC (16-bit | fp32) [N,XH,XW,ld] -> v*mul+add -> crop [0:CH,0:CW] -> bicubic to OH x OW -> optional
  * mul(255).round().clamp(0,255).div(255) -> out fp32 [N,C,OH,OW]. */
 int ur_image_unpad_resize_nchw(const void* x, int x_is_f32, float* out, int N, int C, int XH, int XW, int ld, int CH, int CW,
-                               int OH, int OW, float mul, float add, int quantize, ur_stream_t stream);
+                               int OH, int OW, float mul, float add, int quantize, int dtype, ur_stream_t stream);
 /* z = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale; moments NHWC fp32 [M, ld] (mean | logvar) */
-int ur_vae_sample(const float* moments, int ld, const float* noise_nchw, float* z_nhwc, void* z_bf16, int N,
-                  int HW, int Clat, int Cpad, float scale, ur_stream_t stream);
-/* zt = sa * z0 + sb * noise (DDPMScheduler.add_noise, unifie.py:88); fp32 NHWC state + bf16 copy */
-int ur_add_noise(const float* z0, const float* noise_nchw, float* zt, void* zt_bf16, int N, int HW, int Clat,
-                 int Cpad, float sa, float sb, ur_stream_t stream);
-/* DDIM update (unifie.py:150): zt <- c_x*zt + c_e*eps, eps fp32 NHWC [M, ld_eps]; refreshes the bf16 copy */
-int ur_ddim_step(float* zt, const float* eps, int ld_eps, void* zt_bf16, long long M, int Clat, int Cpad,
-                 float c_x, float c_e, ur_stream_t stream);
-/* y_bf16[M][Cpad] = x_f32[M][ld] * mul (latents / scaling_factor before post_quant_conv) */
-int ur_f32_to_bf16_scaled(const float* x, int ld, void* y, long long M, int C, int Cpad, float mul, ur_stream_t stream);
+int ur_vae_sample(const float* moments, int ld, const float* noise_nchw, float* z_nhwc, void* z_16, int N,
+                  int HW, int Clat, int Cpad, float scale, int dtype, ur_stream_t stream);
+/* zt = sa * z0 + sb * noise (DDPMScheduler.add_noise, unifie.py:88); fp32 NHWC state + 16-bit copy */
+int ur_add_noise(const float* z0, const float* noise_nchw, float* zt, void* zt_16, int N, int HW, int Clat,
+                 int Cpad, float sa, float sb, int dtype, ur_stream_t stream);
+/* DDIM update (unifie.py:150): zt <- c_x*zt + c_e*eps, eps fp32 NHWC [M, ld_eps]; refreshes the 16-bit copy */
+int ur_ddim_step(float* zt, const float* eps, int ld_eps, void* zt_16, long long M, int Clat, int Cpad,
+                 float c_x, float c_e, int dtype, ur_stream_t stream);
+/* y_16[M][Cpad] = x_f32[M][ld] * mul (latents / scaling_factor before post_quant_conv) */
+int ur_f32_to_bf16_scaled(const float* x, int ld, void* y, long long M, int C, int Cpad, float mul, int dtype, ur_stream_t stream);
 
 /* ---- live per-kernel-family timing (HIP events on the launch stream) ------------------------------*/
 int ur_profile_enable(int on);

@@ -156,6 +156,10 @@ class SkipConnectedAutoEncoder(nn.Module):
     def decode(self, latents, res_samples, task):
         dec = self.vae.decoder
         h = dec.mid_block(dec.conv_in(self.vae.post_quant_conv(latents / self.vae.scaling_factor)))
+        if not hasattr(dec, "task_editors"):          # tedit=None: the decoder forward is not patched (autoencoder.py:107-110)
+            for blk in dec.up_blocks:
+                h = blk(h)
+            return (dec.conv_out(F.silu(dec.conv_norm_out(h))) + 1) / 2
         cond = dec.task_prompts[task].unsqueeze(0).expand(latents.shape[0], -1, -1)
         for i, blk in enumerate(dec.up_blocks[:-1]):
             h, cond = dec.task_editors[i](h, res_samples[-i - 1], cond)

@@ -59,3 +59,28 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_ctypes_struct_layout_matches_the_header(tmp_path):
+    """ur_conv_desc / ur_conv_plan are filled from Python through ctypes mirrors: every field offset and the total size must
+    equal what a C compiler lays out for the header's structs."""
+    import shutil
+    import subprocess
+    from unirestore_amd import capi
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [f[0] for f in capi.ConvDesc._fields_]
+    lines = "".join(f'  printf("{n} %zu\\n", offsetof(ur_conv_desc, {n}));\n' for n in fields)
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "unirestore_hip.h"\nint main(void) {\n' + lines +
+                   '  printf("sizeof %zu\\n", sizeof(ur_conv_desc));\n  printf("plan %zu\\n", sizeof(ur_conv_plan));\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    r = subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for n in fields:
+        assert int(out[n]) == getattr(capi.ConvDesc, n).offset, n
+    assert int(out["sizeof"]) == ctypes.sizeof(capi.ConvDesc) and int(out["plan"]) == ctypes.sizeof(capi.ConvPlan)

@@ -1,0 +1,141 @@
+"""Every BASELINE.json configuration at FULL model size on the GPU (-m gpu), against the CPU oracle with identical weights.
+
+  configs[0]  256x256 (-> 512x512 inside forward), 4 DDIM steps, B=1
+  configs[1]  512x512, 20 steps, B=8  -> its B=1 / 1-step sample against the oracle (the oracle needs ~25 s per step-set on
+  configs[2]  = configs[1] per GPU       the box's host cores; 20 steps x 8 images would be an hour), both 16-bit types
+  configs[3]  1024x1024, task "seg", B=1 per GPU, 1-step sample (latents 128x128, 16384 tokens)
+  configs[4]  512x512, 50 steps, fp16: 50-step trajectory finite + deterministic at full size, 50-step PARITY on the tiny model
+  + a 300x500 input (bicubic resize -> 512x853 -> reflect pad -> 512x896 -> un-pad -> resize back) and the config entry point.
+
+Tolerances = 1.5 x the values measured on MI355X (comments), per 16-bit type; the fp16 path meets the north-star 1e-3.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from golden_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# measured rel-L2 (z0, zt, image) on MI355X x 1.5, full-size random-weight model
+TOL = {"bf16": (9e-3, 7e-3, 7e-3), "fp16": (1.2e-3, 1e-3, 1e-3)}
+
+
+def _kw(steps):
+    return dict(frenc=dict(type="CFRM"), cnet=dict(type="scedit", num_inference_steps=steps),
+                tedit=dict(type="TFA", prompt_len=1, task=["ir", "cls", "seg"]))
+
+
+@pytest.fixture(scope="module")
+def full():
+    """(oracle on the host, HIP model on cuda:0) - full-size architecture, the same seeded random weights."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle.model import DiffUIE as ODiffUIE
+    dev = torch.device("cuda", 0)
+    m = bench.build_model(1, dev, 0, 1)
+    o = ODiffUIE(**_kw(1)).eval()
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    torch.set_num_threads(os.cpu_count() or 8)
+    return o, m
+
+
+def _oracle(o, img, task, noise, steps):
+    from oracle import schedule as osched
+    o.num_inference_steps, o.timesteps = steps, osched.ddim_timesteps(steps)
+    with torch.no_grad():
+        return o(img, task, noise=noise, return_latents=True)
+
+
+def _check(o, m, img, task, steps, dtypes=("bf16", "fp16"), label=""):
+    from unirestore_amd.modules import resize_pad_plan
+    g = torch.Generator().manual_seed(1234)
+    h, w, ph, pw = resize_pad_plan(*img.shape[-2:])
+    shp = (img.shape[0], 4, (h + ph) // 8, (w + pw) // 8)
+    noise = (torch.randn(shp, generator=g), torch.randn(shp, generator=g))
+    ref = _oracle(o, img, task, noise, steps)
+    m.set_num_inference_steps(steps)
+    for dt in dtypes:
+        m.set_dtype(dt)
+        got = m(img, task, noise=noise, return_latents=True)
+        e = [rel_l2(a.cpu(), b) for a, b in zip(got, ref)]          # (image, z0, zt)
+        print(f"{label} [{dt}] rel-L2 image {e[0]:.2e} z0 {e[1]:.2e} zt {e[2]:.2e}")
+        assert got[0].shape == img.shape and bool(torch.isfinite(got[0]).all())
+        tz0, tzt, timg = TOL[dt]
+        assert e[1] < tz0 and e[2] < tzt and e[0] < timg, (label, dt, e)
+    m.set_dtype("bf16")
+
+
+def test_config1_sample_512_one_step(full):
+    """The sample bench.py reports as parity_vs_oracle: B=1, 512x512, 1 DDIM step (measured bf16 5.4e-3 / 4.0e-3 / 4.2e-3)."""
+    o, m = full
+    img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(42))
+    _check(o, m, img, "ir", 1, label="configs[1] sample 512x512 / 1 step")
+
+
+def test_config0_256_four_steps(full):
+    o, m = full
+    img = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(43))
+    _check(o, m, img, "ir", 4, label="configs[0] 256x256 / 4 steps")
+
+
+def test_resized_padded_300x500(full):
+    o, m = full
+    img = torch.rand(1, 3, 300, 500, generator=torch.Generator().manual_seed(44))
+    _check(o, m, img, "cls", 1, label="300x500 -> 512x853 -> pad 512x896 / 1 step")
+
+
+def test_config3_seg_1024_one_step(full):
+    o, m = full
+    img = torch.rand(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(45))
+    _check(o, m, img, "seg", 1, dtypes=("bf16",), label="configs[3] 1024x1024 seg / 1 step")
+
+
+def test_config4_fifty_steps_fp16_full_size(full):
+    """50 DDIM steps in fp16 at full size: finite, in range, bit-identical on a second run (graph replay)."""
+    _, m = full
+    m.set_num_inference_steps(50)
+    m.set_dtype("fp16")
+    g = torch.Generator().manual_seed(46)
+    from unirestore_amd.data import degrade
+    hq = torch.rand(3, 3, 512, 512, generator=g)
+    lq = torch.stack([degrade(hq[i], k, g) for i, k in enumerate(("noise", "haze", "lowlight"))])     # the mixed-degradation batch
+    nz = (torch.randn(3, 4, 64, 64, generator=g), torch.randn(3, 4, 64, 64, generator=g))
+    a = m(lq, "ir", noise=nz, return_latents=True)
+    b = m(lq, "ir", noise=nz, return_latents=True)
+    assert all(bool(torch.isfinite(t).all()) for t in a) and all(torch.equal(x, y) for x, y in zip(a, b))
+    assert float(a[0].abs().max()) < 50.0                     # a diverged trajectory would blow up long before 50 steps
+    m.set_dtype("bf16")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_config4_fifty_steps_parity_tiny(dtype):
+    """50-step DDIM trajectory against the oracle (tiny configuration, where the oracle takes seconds)."""
+    from oracle.model import DiffUIE as ODiffUIE
+    from tiny_cfg import TINY, model_kwargs, randomise_
+    import unirestore_amd.modules as M
+    o = randomise_(ODiffUIE(**model_kwargs(50), **TINY).eval(), 11)
+    p = M.DiffUIE(**model_kwargs(50), **TINY, dtype=dtype).eval()
+    p.load_state_dict(o.state_dict())
+    assert p.timesteps.tolist() == list(range(999, 0, -20))
+    g = torch.Generator().manual_seed(47)
+    img = torch.rand(2, 3, 64, 64, generator=g)
+    nz = (torch.randn(2, 4, 64, 64, generator=g), torch.randn(2, 4, 64, 64, generator=g))
+    oy = o(img, "ir", noise=nz, return_latents=True)
+    py = p(img, "ir", noise=nz, return_latents=True)
+    e = [rel_l2(a.cpu(), b) for a, b in zip(py, oy)]
+    print(f"50-step tiny [{dtype}] rel-L2 image {e[0]:.2e} z0 {e[1]:.2e} zt {e[2]:.2e}")
+    lim = 1.2e-2 if dtype == "bf16" else 1.5e-3               # 50 steps accumulate: measured bf16 ~8e-3, fp16 ~1e-3
+    assert max(e) < lim, e
+
+
+def test_cli_validate_config0():
+    """configs/val_pir_256_4step.yaml through the config entry point (model build, crop, restore, 8-bit quantise, metrics)."""
+    from unirestore_amd import cli
+    cfg = cli.load_config(os.path.join(ROOT, "configs", "val_pir_256_4step.yaml"))
+    res = cli.validate(cfg, max_batches=3)
+    assert res["output_finite"] and res["images"] == 3 and res["dtype"] == "bf16" and res["denoise_steps"] == 4
+    assert res["images_per_s"] and res["images_per_s"] > 1.0 and 0.0 < res["val_lq/ssim"] <= 1.0

@@ -25,6 +25,7 @@ def test_broadcast_shard_gather_world2():
         assert p.returncode == 0, err[-2000:]
         v = json.loads(out.strip().splitlines()[-1])
         assert v["same"] and v["moved"] > 0 and v["ragged_ok"] and v["even_ok"], v
+        assert v["tree_same"] and v["tree_bytes"] > 1_000_000 and v["forms_agree"] and v["data_ok"], v
 
 
 def test_shard_range_covers_everything():

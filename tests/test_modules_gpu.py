@@ -1,6 +1,10 @@
 """Module-level parity on the GPU: HIP-backed operator classes vs (a) the reference-generated golden vectors and
-(b) the CPU oracle with identical weights.  Tolerances are rel-L2 on bf16 pipelines (each op rounds its output to
-bf16, ~1e-3 RMS per op); they are stated next to each check.
+(b) the CPU oracle with identical weights, for both 16-bit compute types.
+
+Tolerances are rel-L2 and stated next to each check.  They are set to <= 1.5x the value MEASURED on MI355X (recorded in the
+comments), so a numerical regression of that size fails: the measured values themselves sit where the CPU error budget
+(tests/test_error_budget.py, oracle/emulate.py) says 16-bit operands + 16-bit stored activations must land - bf16 4-6e-3,
+fp16 5-8e-4.  The north-star 1e-3 is met by the fp16 path; bf16 operands alone cost ~3e-3 whatever the implementation.
 """
 import pytest
 import torch
@@ -55,13 +59,20 @@ def test_cfrm_golden(M, name):
     assert rel_l2(m(i["x"]).cpu(), o["y"]) < 1.5e-2
 
 
-def _pair(M, seed=0, steps=2):
+def _pair(M, seed=0, steps=2, dtype="bf16", kw=None):
     from oracle.model import DiffUIE as ODiffUIE
     torch.manual_seed(seed)
-    o = randomise_(ODiffUIE(**model_kwargs(steps), **TINY).eval(), seed)
-    p = M.DiffUIE(**model_kwargs(steps), **TINY, use_graph=False).eval()
+    kw = kw or model_kwargs(steps)
+    o = randomise_(ODiffUIE(**kw, **TINY).eval(), seed)
+    p = M.DiffUIE(**kw, **TINY, use_graph=False, dtype=dtype).eval()
     p.load_state_dict(o.state_dict())
     return o, p
+
+
+# measured on MI355X (rel-L2 vs the fp32 oracle, tiny configuration): tolerance = 1.5 x measured, per compute dtype
+TOL = {"bf16": dict(ctrl=9e-3, eps=9e-3, z=6e-3, res=8e-3, img=8e-3, fwd_z0=9e-3, fwd_zt=7e-3, fwd_img=6e-3),
+       "fp16": dict(ctrl=1.2e-3, eps=1.2e-3, z=9e-4, res=1.2e-3, img=1.2e-3, fwd_z0=1.2e-3, fwd_zt=1e-3, fwd_img=1e-3)}
+DTYPES = ["bf16", "fp16"]
 
 
 def test_state_dict_names_match_oracle(M):
@@ -69,8 +80,11 @@ def test_state_dict_names_match_oracle(M):
     assert list(o.state_dict().keys()) == list(p.state_dict().keys())
 
 
-def test_controller_and_unet_step(M):
-    o, p = _pair(M, 1)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_controller_and_unet_step(M, dtype):
+    o, p = _pair(M, 1, dtype=dtype)
+    from unirestore_amd import ops
+    ops.set_dtype(dtype)
     g = torch.Generator().manual_seed(5)
     z0, zt = torch.randn(2, 4, 16, 24, generator=g), torch.randn(2, 4, 16, 24, generator=g)
     ts = torch.tensor([749])
@@ -78,33 +92,38 @@ def test_controller_and_unet_step(M):
         oc = o.controller(z0, ts)
         oe = o.base_model(zt, oc, ts)
     pc = p.controller(z0, ts)
-    for k in oc:
-        assert rel_l2(pc[k].cpu(), oc[k]) < 2e-2, k
+    e = {k: rel_l2(pc[k].cpu(), oc[k]) for k in oc}
     pe = p.base_model(zt, oc, ts)
-    assert rel_l2(pe.cpu(), oe) < 2e-2
+    e["eps"] = rel_l2(pe.cpu(), oe)
+    print(f"controller/unet rel-L2 [{dtype}]:", e)
+    assert all(v < TOL[dtype]["ctrl"] for k, v in e.items() if k != "eps") and e["eps"] < TOL[dtype]["eps"], e
 
 
-def test_autoencoder_encode_decode(M):
-    o, p = _pair(M, 2)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_autoencoder_encode_decode(M, dtype):
+    o, p = _pair(M, 2, dtype=dtype)
+    from unirestore_amd import ops
+    ops.set_dtype(dtype)
     g = torch.Generator().manual_seed(6)
     img, noise = torch.rand(2, 3, 64, 128, generator=g), torch.randn(2, 4, 8, 16, generator=g)
     with torch.no_grad():
         oz, ores = o.ae.encode(img, enable_fr=True, noise=noise)
         oimg = o.ae.decode(oz, ores, "seg")
     pz, pres = p.ae.encode(img, enable_fr=True, noise=noise)
-    assert rel_l2(pz.cpu(), oz) < 2e-2
-    for a, b in zip(pres, ores):
-        assert rel_l2(a.cpu(), b) < 2e-2
+    e = dict(z=rel_l2(pz.cpu(), oz), res=max(rel_l2(a.cpu(), b) for a, b in zip(pres, ores)))
     pimg = p.ae.decode(oz, ores, "seg")
-    assert rel_l2(pimg.cpu(), oimg) < 2e-2
+    e["img"] = rel_l2(pimg.cpu(), oimg)
+    print(f"autoencoder rel-L2 [{dtype}]:", e)
+    assert e["z"] < TOL[dtype]["z"] and e["res"] < TOL[dtype]["res"] and e["img"] < TOL[dtype]["img"], e
     with pytest.raises(KeyError):
         p.ae.decode(oz, ores, "nope")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_full_forward_tiny(M, use_graph):
+def test_full_forward_tiny(M, use_graph, dtype):
     """Whole DiffUIE.forward (resize -> pad -> encode+CFRM -> 2 DDIM steps -> decode+TFA -> unpad -> resize)."""
-    o, p = _pair(M, 3, steps=2)
+    o, p = _pair(M, 3, steps=2, dtype=dtype)
     p.use_graph = use_graph
     g = torch.Generator().manual_seed(7)
     img = torch.rand(1, 3, 96, 80, generator=g)           # upscaled to 614x512, padded to 640x512
@@ -112,13 +131,14 @@ def test_full_forward_tiny(M, use_graph):
     oy, oz0, ozt = o(img, "ir", noise=noise, return_latents=True)
     py, pz0, pzt = p(img, "ir", noise=noise, return_latents=True)
     e = dict(z0=rel_l2(pz0.cpu(), oz0), zt=rel_l2(pzt.cpu(), ozt), img=rel_l2(py.cpu(), oy))
-    print("full-forward rel-L2:", e)
+    print(f"full-forward rel-L2 [{dtype}, graph={use_graph}]:", e)
     assert py.shape == img.shape
-    assert e["z0"] < 2e-2 and e["zt"] < 5e-2 and e["img"] < 3e-2
+    t = TOL[dtype]
+    assert e["z0"] < t["fwd_z0"] and e["zt"] < t["fwd_zt"] and e["img"] < t["fwd_img"], e
     if use_graph:                                           # replay with new inputs must track the oracle too
         img2 = torch.rand(1, 3, 96, 80, generator=g)
         oy2 = o(img2, "ir", noise=noise)
-        assert rel_l2(p(img2, "ir", noise=noise).cpu(), oy2) < 3e-2
+        assert rel_l2(p(img2, "ir", noise=noise).cpu(), oy2) < t["fwd_img"]
 
 
 def test_reference_error_behaviour(M):
@@ -146,8 +166,8 @@ def test_runner_validation_step_quantised(M):
     assert q.shape == small.shape
     assert float((q * 255 - (q * 255).round()).abs().max()) < 1e-3
     d = (q - plain.mul(255).round().clamp(0, 255).div(255)).abs()
-    # the two forwards are separate runs of a bf16 pipeline with atomically-ordered sums: code values may move by one step
-    assert d.max() <= 8 / 255 and float(d.mean()) < 1 / 255      # (the kernel itself is checked exactly in test_ops_gpu)
+    # the path is deterministic (no atomics): quantising inside the output kernel == quantising the plain forward's output
+    assert float(d.max()) < 1e-6
     preds, _ = runner.validation_step(p, small, need_crop=True)
     assert len(preds) == 1 and preds[0].shape == small.shape and 0.0 <= float(preds[0].min()) and float(preds[0].max()) <= 1.0
     with pytest.raises(ValueError):
@@ -186,3 +206,98 @@ def test_spade_control_path(M, use_graph):
         oy = o(img, "ir", noise=noise)
     py = p(img, "ir", noise=noise)
     assert py.shape == img.shape and rel_l2(py.cpu(), oy) < 3e-2
+
+
+# ---- determinism, graph hygiene, reference edge cases ----------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_forward_is_bit_deterministic(M, dtype):
+    """No kernel uses atomics: two eager runs, a graph capture and two replays of it agree BIT FOR BIT on the same inputs
+    (the reference is deterministic given the two noise tensors, unifie.py:137-160)."""
+    _, p = _pair(M, 4, steps=2, dtype=dtype)
+    g = torch.Generator().manual_seed(21)
+    img = torch.rand(2, 3, 64, 96, generator=g)
+    h, w, ph, pw = M.resize_pad_plan(64, 96)
+    nz = tuple(torch.randn(2, 4, (h + ph) // 8, (w + pw) // 8, generator=g) for _ in range(2))
+    a = p(img, "ir", noise=nz, return_latents=True)
+    b = p(img, "ir", noise=nz, return_latents=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    p.use_graph = True
+    c = p(img, "ir", noise=nz, return_latents=True)           # capture + first replay
+    d = p(img, "ir", noise=nz, return_latents=True)           # second replay
+    for x, y, z in zip(a, c, d):
+        assert torch.equal(y, z) and torch.equal(x, y)
+
+
+def test_graph_outputs_are_not_aliased(M):
+    """Two same-shape forwards through one captured graph: the first result must survive the second replay (runner.forward
+    keeps [enh_hq, enh_lq]; ADVICE r1 'high')."""
+    from unirestore_amd import runner
+    _, p = _pair(M, 6, steps=1)
+    p.use_graph = True
+    g = torch.Generator().manual_seed(22)
+    a_img, b_img = torch.rand(1, 3, 64, 64, generator=g), torch.rand(1, 3, 64, 64, generator=g)
+    nz = tuple(torch.randn(1, 4, 64, 64, generator=g) for _ in range(2))
+    a = p(a_img, "ir", noise=nz)
+    keep = a.clone()
+    b = p(b_img, "ir", noise=nz)
+    assert a.data_ptr() != b.data_ptr() and torch.equal(a, keep) and not torch.equal(a, b)
+    outs = runner.forward(p, [a_img, b_img], "ir")            # the evaluator's [hq, lq] list-map
+    assert outs[0].data_ptr() != outs[1].data_ptr() and not torch.equal(outs[0], outs[1])
+
+
+def test_adhoc_calls_invalidate_schedule_tables_and_graphs(M):
+    """Controller.forward / ControlledUNet.forward / predict_z0 rebind the per-resnet time tables; a later DiffUIE.forward must
+    rebuild its schedule tables and drop graphs captured against the old ones (ADVICE r1 'medium')."""
+    o, p = _pair(M, 7, steps=2)
+    p.use_graph = True
+    g = torch.Generator().manual_seed(23)
+    img = torch.rand(1, 3, 64, 64, generator=g)
+    nz = tuple(torch.randn(1, 4, 64, 64, generator=g) for _ in range(2))
+    first = p(img, "ir", noise=nz)
+    z = torch.randn(1, 4, 16, 16, generator=g)
+    p.controller(z, torch.tensor([249]))                      # ad-hoc call with a different timestep
+    assert len(p._graphs) == 1
+    again = p(img, "ir", noise=nz)                            # must notice, rebuild and re-capture
+    assert torch.equal(first, again)
+    p.base_model(z, {k: v for k, v in o.controller(z, torch.tensor([499])).items()}, torch.tensor([499]))
+    p.predict_z0(z, z, torch.tensor([749]))
+    assert torch.equal(first, p(img, "ir", noise=nz))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stage1_configuration_without_task_editor(M, dtype):
+    """tedit=None (train_stage1.yaml): the reference keeps the stock VAE decoder (autoencoder.py:107-110) - no task prompts,
+    no TaskFeatureAdapters, the task argument is ignored (ADVICE r1 'medium')."""
+    kw = model_kwargs(2)
+    kw["tedit"] = None
+    o, p = _pair(M, 8, dtype=dtype, kw=kw)
+    assert list(o.state_dict().keys()) == list(p.state_dict().keys()) and not any("task_" in k for k in p.state_dict())
+    g = torch.Generator().manual_seed(24)
+    img = torch.rand(1, 3, 64, 64, generator=g)
+    nz = tuple(torch.randn(1, 4, 64, 64, generator=g) for _ in range(2))
+    oy = o(img, "ir", noise=nz)
+    for use_graph in (False, True):
+        p.use_graph = use_graph
+        assert rel_l2(p(img, "anything", noise=nz).cpu(), oy) < TOL[dtype]["fwd_img"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_training_side_forwards_diffuse_and_predict_z0(M, dtype):
+    """DiffUIE.diffuse (unifie.py:77-89) and predict_z0 (:91-105) with per-sample timesteps vs the oracle."""
+    o, p = _pair(M, 9, dtype=dtype)
+    g = torch.Generator().manual_seed(25)
+    lat, cond = torch.randn(3, 4, 16, 16, generator=g), torch.randn(3, 4, 16, 16, generator=g)
+    noise = torch.randn(3, 4, 16, 16, generator=g)
+    ts = torch.tensor([249, 999, 499])
+    on, _, ot = o.diffuse(lat, ts, noise)
+    pn, pnoise, pt = p.diffuse(lat, ts, noise)
+    assert pt.tolist() == ot.tolist() and torch.equal(pnoise.cpu(), noise) and rel_l2(pn.cpu(), on) < 1e-6     # fp32 arithmetic
+    with torch.no_grad():
+        oz = o.predict_z0(on, cond, ts)
+    pz = p.predict_z0(on, cond, ts)
+    e = rel_l2(pz.cpu(), oz)
+    print(f"predict_z0 rel-L2 [{dtype}]:", e)
+    assert e < TOL[dtype]["eps"]
+    rnd, _, tt = p.diffuse(lat)                                # random training timesteps come from train_timesteps
+    assert set(tt.tolist()) <= {249, 499, 749, 999} and rnd.shape == lat.shape

@@ -11,7 +11,6 @@ for (h, cin, cout) in [(64, 320, 320), (32, 640, 640), (16, 1280, 1280)]:
     bias_row = torch.randn(cout, device="cuda")
     def run(**kw):
         def f():
-            ops.arena().off = 0
             return ops.conv(x, pc, **kw)
         return gtime(f)
     print(f"{h}x{h} {cin}->{cout}: plain {run():.1f}  +res {run(residual=r):.1f}  +gn {run(gn=True):.1f}  +res+gn {run(residual=r, gn=True):.1f}  +bias-row {run(bias=bias_row):.1f} us")

@@ -18,7 +18,6 @@ print("1x1 tiny, bias+residual   us/launch:", round(gtime(lambda: ops.conv(x, pc
 print("3x3 tiny, bias            us/launch:", round(gtime(lambda: ops.conv(x, pc3, out=y), reps=200), 2))
 g = torch.ones(64, device="cuda"); b = torch.zeros(64, device="cuda")
 def gn():
-    ops.arena().reset()
     return ops.group_norm(x, g, b, 32, 1e-5, True)
 print("GN tiny (stats+finalize+apply + arena fill) us:", round(gtime(gn, reps=100), 2))
 q = torch.randn(1, 64, 192, device="cuda").to(torch.bfloat16); vt = torch.randn(1, 64, 64, device="cuda").to(torch.bfloat16)

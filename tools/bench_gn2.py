@@ -7,7 +7,6 @@ B = 8
 for (h, c) in [(64, 320), (64, 640), (64, 960), (32, 640), (32, 1280), (32, 1920), (16, 1280), (8, 1280), (512, 128), (256, 256)]:
     x0 = torch.randn(B, h, h, c, device="cuda").to(torch.bfloat16)
     pc = ops.pack_conv(torch.eye(c).view(c, c, 1, 1), None, "cuda")
-    ops.arena().reset()
     x = ops.conv(x0, pc, gn=True)           # leaves fused / fallback channel sums on x
     ga, be = torch.randn(c, device="cuda"), torch.randn(c, device="cuda")
     us = gtime(lambda: ops.group_norm(x, ga, be, 32, 1e-5, True))

@@ -8,7 +8,6 @@ from unirestore_amd import ops
 def run(m, c, n, pair=False):
     x0 = torch.randn(m, c, device="cuda").to(torch.bfloat16)
     pc0 = ops.pack_conv(torch.randn(c, c, 1, 1) / math.sqrt(c), torch.randn(c), "cuda")
-    ops.arena().reset()
     x = ops.linear(x0, pc0, rows=True)
     st, parts = ops.ln_of(x)
     w, b = torch.randn(n, c) / math.sqrt(c), torch.randn(n)

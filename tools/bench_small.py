@@ -10,7 +10,6 @@ def run(m, cin, cout, rows=False):
     pc = ops.pack_conv(torch.randn(cout, cin, 1, 1) / cin ** 0.5, torch.randn(cout), "cuda")
     r = torch.randn(m, cout, device="cuda").to(torch.bfloat16)
     def f():
-        ops.arena().reset()
         ops.linear(x, pc, residual=r, rows=rows)
     us = gtime(f)
     print(f"M{m} K{cin} N{cout} rows={int(rows)}  {us:7.1f} us  {2.0*m*cin*cout/us/1e6:7.1f} TF/s")

@@ -9,7 +9,6 @@ def run(b, hw, cin, cout, gn=True):
     x = torch.randn(b, hw, hw, cin, device="cuda").to(torch.bfloat16)
     pc = ops.pack_conv(torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.randn(cout), "cuda")
     def f():
-        ops.arena().reset()
         ops.conv(x, pc, gn=gn)
     us = gtime(f)
     print(f"c3 B{b} {hw}x{hw} {cin}->{cout}  {us:7.1f} us  {2.0*b*hw*hw*cin*cout*9/us/1e6:7.1f} TF/s")

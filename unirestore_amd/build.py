@@ -13,8 +13,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libunirestore_hip.so")
-SOURCES = ["igemm_v1a.hip", "igemm_v1b.hip", "igemm_v2.hip", "igemm_halo.hip", "igemm_g1.hip", "igemm.hip", "runtime.hip", "norms.hip",
-           "attention.hip", "elementwise.hip"]
+IGEMM_UNITS = ["igemm_v2.hip", "igemm_halo.hip", "igemm_v1a.hip", "igemm_v1b.hip", "igemm_g1.hip"]     # slowest first
+# (source, extra flags, object name): every igemm instantiation unit is built once per 16-bit type
+SOURCES = [(u, [f"-DUR_TU_F16={t}"], u.replace(".hip", "_f16.o" if t else "_bf16.o")) for u in IGEMM_UNITS for t in (0, 1)] + \
+          [(u, [], u.replace(".hip", ".o")) for u in ("igemm.hip", "attention.hip", "norms.hip", "elementwise.hip", "runtime.hip")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-Wno-unused-result"]
 
@@ -41,9 +43,10 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     cc = _hipcc()
 
-    def one(src):
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
+    def one(unit):
+        src, extra, oname = unit
+        obj = os.path.join(objdir, oname)
+        cmd = [cc, *FLAGS, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -55,11 +58,11 @@ def build(force=False, verbose=True):
                 name = m.group(1)
             m = re.search(r"(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
             if m and name:
-                usage.setdefault(f"{src}:{name}", {})[m.group(1).split(" ")[0]] = int(m.group(2))
+                usage.setdefault(f"{oname}:{name}", {})[m.group(1).split(" ")[0]] = int(m.group(2))
         return obj
 
     usage = {}
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 8)) as ex:
         objs = list(ex.map(one, SOURCES))
     with open(os.path.join(objdir, "resource_usage.json"), "w") as f:
         json.dump(usage, f, indent=0, sort_keys=True)

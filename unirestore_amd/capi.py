@@ -10,13 +10,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunirestore_hip.so")
 
 UR_ACT_NONE, UR_ACT_SILU, UR_ACT_GELU, UR_ACT_GEGLU, UR_ACT_GATE, UR_ACT_TANH, UR_ACT_RELU = range(7)
+UR_DT_BF16, UR_DT_F16 = 0, 1
+UR_E_INVALID, UR_E_UNSUPPORTED = -1, -2
 
 
 class ConvDesc(C.Structure):
     """Mirror of `ur_conv_desc` (field order and types must match the header exactly)."""
     _fields_ = [
         ("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
-        ("y", C.c_void_p), ("yt", C.c_void_p), ("colsum", C.c_void_p), ("gn_stats", C.c_void_p),
+        ("y", C.c_void_p), ("yt", C.c_void_p), ("gn_part", C.c_void_p), ("gn_ab", C.c_void_p), ("gn_silu", C.c_int),
         ("row_stats", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int), ("ln_parts", C.c_int),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
@@ -27,11 +29,17 @@ class ConvDesc(C.Structure):
         ("OH", C.c_int), ("OW", C.c_int),
         ("upsample2x", C.c_int), ("act", C.c_int), ("out_f32", C.c_int),
         ("n_split", C.c_int), ("t_rows", C.c_int), ("t_ld", C.c_int),
-        ("out_scale", C.c_float), ("colsum_scale", C.c_float),
+        ("out_scale", C.c_float),
         ("nbatch", C.c_int),
         ("bs_x", C.c_longlong), ("bs_x2", C.c_longlong), ("bs_w", C.c_longlong), ("bs_bias", C.c_longlong),
         ("bs_y", C.c_longlong), ("bs_r", C.c_longlong), ("k_chunk_major", C.c_int), ("bias_img_stride", C.c_longlong),
+        ("dtype", C.c_int),
     ]
+
+
+class ConvPlan(C.Structure):
+    """Mirror of `ur_conv_plan`."""
+    _fields_ = [("row_stat_parts", C.c_int), ("gn_parts", C.c_int), ("gn_fused", C.c_int), ("prologue_ok", C.c_int)]
 
 
 _P, _I, _F, _LL, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -41,30 +49,37 @@ SIGNATURES = {
     "ur_version": (_I, []),
     "ur_last_error": (C.c_char_p, []),
     "ur_conv2d_nhwc": (_I, [C.POINTER(ConvDesc), _P]),
-    "ur_conv2d_row_stat_parts": (_I, [C.POINTER(ConvDesc)]),
-    "ur_groupnorm_ws_bytes": (_SZ, [_I, _I]),
+    "ur_conv2d_plan": (_I, [C.POINTER(ConvDesc), C.POINTER(ConvPlan)]),
+    "ur_gemm_bias_act": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _I, _P]),
+    "ur_groupconv3x3_nhwc": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _I, _P]),
+    "ur_groupnorm_stats_parts": (_I, [_I, _I, _I]),
+    "ur_groupnorm_ws_bytes": (_SZ, [_I, _I, _I]),
     "ur_groupnorm_ab_bytes": (_SZ, [_I, _I]),
-    "ur_groupnorm_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
-    "ur_layernorm_rows": (_I, [_P, _P, _P, _P, _LL, _I, _F, _P]),
-    "ur_softmax_rows_f32": (_I, [_P, _P, _LL, _I, _I, _P]),
-    "ur_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL, _F, _P]),
-    "ur_dwconv3x3_nhwc": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "ur_avgpool_hw": (_I, [_P, _P, _I, _I, _I, _P]),
-    "ur_scale_channels": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "ur_axpy_channels": (_I, [_P, _P, _P, _P, _LL, _I, _P]),
-    "ur_spade_modulate": (_I, [_P, _P, _I, _P, _P, _LL, _I, _P]),
+    "ur_groupnorm_stats": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ur_instnorm_stats": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ur_groupnorm_finalize": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "ur_groupnorm_apply_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ur_groupnorm_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "ur_layernorm_rows": (_I, [_P, _P, _P, _P, _LL, _I, _F, _I, _P]),
+    "ur_softmax_rows_f32": (_I, [_P, _P, _LL, _I, _I, _I, _P]),
+    "ur_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL, _F, _I, _P]),
+    "ur_dwconv3x3_nhwc": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ur_avgpool_hw": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
+    "ur_scale_channels": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ur_axpy_channels": (_I, [_P, _P, _P, _P, _LL, _I, _I, _P]),
+    "ur_spade_modulate": (_I, [_P, _P, _I, _P, _P, _LL, _I, _I, _P]),
     "ur_linear_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ur_tfa_prompt_update": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ur_vec_mul_group": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "ur_image_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "ur_nhwc_to_nchw_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
-    "ur_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "ur_image_resize_pad_nhwc": (_I, [_P, _P] + [_I] * 9 + [_F, _F, _P]),
-    "ur_image_unpad_resize_nchw": (_I, [_P, _I, _P] + [_I] * 9 + [_F, _F, _I, _P]),
-    "ur_vae_sample": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
-    "ur_add_noise": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
-    "ur_ddim_step": (_I, [_P, _P, _I, _P, _LL, _I, _I, _F, _F, _P]),
-    "ur_f32_to_bf16_scaled": (_I, [_P, _I, _P, _LL, _I, _I, _F, _P]),
+    "ur_image_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ur_nhwc_to_nchw_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
+    "ur_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ur_image_resize_pad_nhwc": (_I, [_P, _P] + [_I] * 9 + [_F, _F, _I, _P]),
+    "ur_image_unpad_resize_nchw": (_I, [_P, _I, _P] + [_I] * 9 + [_F, _F, _I, _I, _P]),
+    "ur_vae_sample": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "ur_add_noise": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P]),
+    "ur_ddim_step": (_I, [_P, _P, _I, _P, _LL, _I, _I, _F, _F, _I, _P]),
+    "ur_f32_to_bf16_scaled": (_I, [_P, _I, _P, _LL, _I, _I, _F, _I, _P]),
     "ur_profile_enable": (_I, [_I]),
     "ur_profile_report": (_I, [C.c_char_p, _SZ]),
 }
@@ -92,6 +107,8 @@ class URError(RuntimeError):
 def check(rc: int):
     if rc != 0:
         msg = lib.ur_last_error().decode("utf-8", "replace")
-        if rc == -1:
+        if rc == UR_E_INVALID:
             raise ValueError(f"unirestore_hip: {msg}")
+        if rc == UR_E_UNSUPPORTED:
+            raise NotImplementedError(f"unirestore_hip (UR_E_UNSUPPORTED): {msg}")
         raise URError(f"unirestore_hip error {rc}: {msg}")

@@ -25,7 +25,7 @@ struct AttnP {
 
 __device__ __forceinline__ int swap23(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
-template <int D>
+template <int D, bool F16>
 #ifndef UR_ATTN_WAVES
 #define UR_ATTN_WAVES 3
 #endif
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
   const uint16_t* V = p.vt + b * p.bs_vt + (long long)h * D * p.ldvt;
 
   // Q fragments (B operand): lane -> query q0 + l31, dims ds*16 + hf*8 .. +7
-  bf16x8 qf[DS];
+  uint4 qf[DS];
   {
     const int qi = min(q0 + l31, p.Tq - 1);
     const uint16_t* qp = Q + (long long)qi * p.ldq + hf * 8;
 #pragma unroll
-    for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
+    for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const uint4*>(qp + ds * 16);
   }
 
   // K / V^T tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1-KiB piece = 8 rows x 128 B per wave
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
       const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
 #pragma unroll
       for (int ds = 0; ds < DS; ++ds) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + row * KROW + (((ds * 2 + hf) ^ sw) << 4));
-        sacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc[f], 0, 0, 0);
+        const uint4 kf = *reinterpret_cast<const uint4*>(ks + row * KROW + (((ds * 2 + hf) ^ sw) << 4));
+        sacc[f] = mfma16<F16>(kf, qf[ds], sacc[f]);
       }
     }
     // register r of fragment f, half hf  <->  key  t*64 + f*32 + 16*(r>>3) + 8*hf + (r&7)
@@ -201,14 +201,13 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
     for (int kk = 0; kk < 4; ++kk) {
       uint4 pk;
       const float* sp = s + kk * 8;
-      pk.x = pack2bf(sp[0], sp[1]); pk.y = pack2bf(sp[2], sp[3]);
-      pk.z = pack2bf(sp[4], sp[5]); pk.w = pack2bf(sp[6], sp[7]);
-      const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+      pk.x = Act<F16>::pack2(sp[0], sp[1]); pk.y = Act<F16>::pack2(sp[2], sp[3]);
+      pk.z = Act<F16>::pack2(sp[4], sp[5]); pk.w = Act<F16>::pack2(sp[6], sp[7]);
 #pragma unroll
       for (int f = 0; f < DF; ++f) {
         const int row = f * 32 + l31;
-        bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs + row * 128 + (((kk * 2 + hf) ^ ((row >> 1) & 7)) << 4));
-        oacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[f], 0, 0, 0);
+        const uint4 vf = *reinterpret_cast<const uint4*>(vs + row * 128 + (((kk * 2 + hf) ^ ((row >> 1) & 7)) << 4));
+        oacc[f] = mfma16<F16>(vf, pk, oacc[f]);
       }
     }
     if (more) store_tile(stage ^ 1);
@@ -228,8 +227,8 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
       for (int g = 0; g < 4; ++g) {
         const int c = f * 32 + 8 * g + 4 * hf;
         *reinterpret_cast<uint2*>(op + c) =
-            make_uint2(pack2bf(oacc[f][g * 4] * inv, oacc[f][g * 4 + 1] * inv),
-                       pack2bf(oacc[f][g * 4 + 2] * inv, oacc[f][g * 4 + 3] * inv));
+            make_uint2(Act<F16>::pack2(oacc[f][g * 4] * inv, oacc[f][g * 4 + 1] * inv),
+                       Act<F16>::pack2(oacc[f][g * 4 + 2] * inv, oacc[f][g * 4 + 3] * inv));
       }
   }
 }
@@ -238,9 +237,10 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
 
 extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk, int D,
                                 int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k, long long bs_vt,
-                                long long bs_o, float scale, ur_stream_t stream) {
+                                long long bs_o, float scale, int dtype, ur_stream_t stream) {
   UR_REQUIRE(q && k && vt && o, "null pointer");
   UR_REQUIRE(D == 64 || D == 128, "head dim must be 64 or 128 (use the GEMM path otherwise)");
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "empty problem");
   UR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Tk, "leading dims");
   AttnP p;
@@ -255,15 +255,16 @@ extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, vo
   dim3 grid((Tq + 127) / 128, B * H), block(256);
   if (D == 64) {
     constexpr int lds = 2 * (64 * 128 + 64 * 128);
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, lds, s, p);
+    UR_DT_SWITCH(dtype, hipLaunchKernelGGL((attn_fwd_kernel<64, F16>), grid, block, lds, s, p));
   } else {
     constexpr int lds = 2 * (64 * 256 + 128 * 128);
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, lds, s, p);
+    UR_DT_SWITCH(dtype, hipLaunchKernelGGL((attn_fwd_kernel<128, F16>), grid, block, lds, s, p));
   }
   return ur::check_launch("ur_attention_fwd");
 }

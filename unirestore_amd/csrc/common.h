@@ -30,6 +30,50 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
 }
 
+
+// ------------------------------------------------------------------------------------------ 16-bit activation types
+// Every kernel that touches 16-bit activations / weights is a template on F16: false = bf16 (8-bit mantissa, fp32 range),
+// true = IEEE fp16 (11-bit mantissa: ~8x smaller rounding error per stored tensor, range +-65504 - conversions saturate).
+// Both feed v_mfma_f32_32x32x16_{bf16,f16} at the same rate with fp32 accumulation.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+template <bool F16> struct Act;
+template <> struct Act<false> {
+  static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ float one(uint16_t v) { return bf2f(v); }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack2bf(a, b); }
+};
+template <> struct Act<true> {
+  static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+  static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+  static __device__ __forceinline__ float one(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {     // round-to-nearest-even, saturating (no inf)
+    f32x2_t v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+  }
+};
+template <bool F16> __device__ __forceinline__ uint16_t f2h16(float f) { return (uint16_t)(Act<F16>::pack2(f, 0.f) & 0xffffu); }
+template <bool F16> __device__ __forceinline__ void unpack8t(const uint4& v, float* f) {
+  f[0] = Act<F16>::lo(v.x); f[1] = Act<F16>::hi(v.x); f[2] = Act<F16>::lo(v.y); f[3] = Act<F16>::hi(v.y);
+  f[4] = Act<F16>::lo(v.z); f[5] = Act<F16>::hi(v.z); f[6] = Act<F16>::lo(v.w); f[7] = Act<F16>::hi(v.w);
+}
+template <bool F16> __device__ __forceinline__ uint4 pack8t(const float* f) {
+  return make_uint4(Act<F16>::pack2(f[0], f[1]), Act<F16>::pack2(f[2], f[3]), Act<F16>::pack2(f[4], f[5]), Act<F16>::pack2(f[6], f[7]));
+}
+// one 32x32x16 MFMA step on 16-bit operands held as raw 128-bit fragments
+template <bool F16> __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// host-side dispatch on a UR_DT_* value: BODY sees `constexpr bool F16`
+#define UR_DT_SWITCH(dtype, ...)                                   \
+  do {                                                             \
+    if ((dtype) == UR_DT_F16) { constexpr bool F16 = true; __VA_ARGS__; } \
+    else { constexpr bool F16 = false; __VA_ARGS__; }              \
+  } while (0)
+#define UR_REQUIRE_DT(dtype) UR_REQUIRE((dtype) == UR_DT_BF16 || (dtype) == UR_DT_F16, "dtype must be UR_DT_BF16 or UR_DT_F16")
+
 // ------------------------------------------------------------------------------------------ math
 // SiLU with the hardware reciprocal (1 ulp) instead of an IEEE division (~10 instructions)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
@@ -85,7 +129,8 @@ int check_launch(const char* what);
 // replay on small private-pool buffers (ROCm 7.2), so the library never emits memset nodes.
 void zero_async(void* ptr, size_t bytes, hipStream_t s);
 // per-(image, channel) sum / sum-of-squares of a dense NHWC bf16 tensor, accumulated into fp64 stats[N][C][2] (norms.hip)
-int gn_stats_launch(const void* x, double* stats, int N, int HW, int C, hipStream_t s);
+int gn_stats_parts(int N, int HW, int C);
+int gn_stats_launch(const void* x, float* part, int N, int HW, int C, int dtype, hipStream_t s);
 
 // Live timing: one (start, stop) hipEvent pair around each launch, on the launch stream.
 struct ProfScope {

@@ -4,6 +4,7 @@
 namespace {
 
 // ---- depthwise 3x3 (pad 1) + bias (+ SimpleGate): one thread = 8 channels of one output pixel ------
+template <bool F16>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, uint16_t* __restrict__ y, int N,
                                                         int H, int W, int C, int gate) {
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restri
           if ((unsigned)iw >= (unsigned)W) continue;
           uint4 raw = *reinterpret_cast<const uint4*>(x + (((long long)n * H + ih) * W + iw) * C + c0);
           float f[8];
-          unpack8(raw, f);
+          unpack8t<F16>(raw, f);
           const float* wp = w + (dy * 3 + dx) * C + c0;
           float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
           a[0] += f[0] * w0.x; a[1] += f[1] * w0.y; a[2] += f[2] * w0.z; a[3] += f[3] * w0.w;
@@ -45,39 +46,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[0][e] *= acc[1][e];
     }
-    *reinterpret_cast<uint4*>(y + pix * Cout + v * 8) = pack8(acc[0]);
+    *reinterpret_cast<uint4*>(y + pix * Cout + v * 8) = pack8t<F16>(acc[0]);
   }
 }
 
-// ---- mean over HW -> fp32 [N][C]: (pixel chunk, image, channel slab) grid, LDS combine, one atomic per channel/block ---
-__global__ __launch_bounds__(256) void avgpool_kernel(const uint16_t* __restrict__ x, float* __restrict__ out, int HW, int C,
-                                                      int pix_per_block, float inv, int CVS) {
-  __shared__ float lds[256];
-  const int n = blockIdx.y, t = threadIdx.x, CV = C >> 3, R = 256 / CVS;
-  const int r = t / CVS, vl = t - r * CVS, v = blockIdx.z * CVS + vl;
-  const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
-  for (int i = t; i < CVS * 8; i += 256) lds[i] = 0.f;
-  __syncthreads();
-  if (r < R && v < CV) {
-    const uint16_t* xi = x + (long long)n * HW * C + v * 8;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = p_begin + r; p < p_end; p += R) {
-      uint4 raw = *reinterpret_cast<const uint4*>(xi + (long long)p * C);
-      float f[8];
-      unpack8(raw, f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += f[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&lds[vl * 8 + e], s[e]);
-  }
-  __syncthreads();
-  for (int i = t; i < CVS * 8; i += 256) {
-    const int c = blockIdx.z * CVS * 8 + i;
-    if (c < C) atomicAdd(out + (long long)n * C + c, lds[i] * inv);
-  }
-}
-
+template <bool F16>
 __global__ __launch_bounds__(256) void scale_channels_kernel(const uint16_t* __restrict__ x, const float* __restrict__ s,
                                                              const uint16_t* __restrict__ res, uint16_t* __restrict__ y,
                                                              long long HWCV, int CV, long long totalv) {
@@ -86,36 +59,38 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const uint16_t* __r
     const long long n = i / HWCV;
     uint4 raw = *reinterpret_cast<const uint4*>(x + i * 8);
     float f[8];
-    unpack8(raw, f);
+    unpack8t<F16>(raw, f);
     const float* sp = s + (n * CV + v) * 8;
     float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
     f[0] *= s0.x; f[1] *= s0.y; f[2] *= s0.z; f[3] *= s0.w; f[4] *= s1.x; f[5] *= s1.y; f[6] *= s1.z; f[7] *= s1.w;
     if (res) {
       float r[8];
-      unpack8(*reinterpret_cast<const uint4*>(res + i * 8), r);
+      unpack8t<F16>(*reinterpret_cast<const uint4*>(res + i * 8), r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] += r[e];
     }
-    *reinterpret_cast<uint4*>(y + i * 8) = pack8(f);
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8t<F16>(f);
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void axpy_channels_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
                                                             const float* __restrict__ s, uint16_t* __restrict__ y, int CV,
                                                             long long totalv) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < totalv; i += (long long)gridDim.x * 256) {
     const int v = (int)(i % CV);
     float fa[8], fb[8];
-    unpack8(*reinterpret_cast<const uint4*>(a + i * 8), fa);
-    unpack8(*reinterpret_cast<const uint4*>(b + i * 8), fb);
+    unpack8t<F16>(*reinterpret_cast<const uint4*>(a + i * 8), fa);
+    unpack8t<F16>(*reinterpret_cast<const uint4*>(b + i * 8), fb);
     const float* sp = s + v * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) fa[e] += fb[e] * sp[e];
-    *reinterpret_cast<uint4*>(y + i * 8) = pack8(fa);
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8t<F16>(fa);
   }
 }
 
 // SPADE modulation: y = n * (1 + gamma) + beta (+ residual), gamma | beta from one fused conv output [rows][2C]
+template <bool F16>
 __global__ __launch_bounds__(256) void spade_modulate_kernel(const uint16_t* __restrict__ n, const uint16_t* __restrict__ gb, int ldgb,
                                                              const uint16_t* __restrict__ res, uint16_t* __restrict__ y, int CV,
                                                              long long totalv) {
@@ -123,13 +98,13 @@ __global__ __launch_bounds__(256) void spade_modulate_kernel(const uint16_t* __r
     const long long r = i / CV;
     const int v = (int)(i - r * CV);
     float fn[8], fg[8], fb[8], fr[8];
-    unpack8(*reinterpret_cast<const uint4*>(n + i * 8), fn);
-    unpack8(*reinterpret_cast<const uint4*>(gb + r * ldgb + v * 8), fg);
-    unpack8(*reinterpret_cast<const uint4*>(gb + r * ldgb + (CV + v) * 8), fb);
-    if (res) unpack8(*reinterpret_cast<const uint4*>(res + i * 8), fr);
+    unpack8t<F16>(*reinterpret_cast<const uint4*>(n + i * 8), fn);
+    unpack8t<F16>(*reinterpret_cast<const uint4*>(gb + r * ldgb + v * 8), fg);
+    unpack8t<F16>(*reinterpret_cast<const uint4*>(gb + r * ldgb + (CV + v) * 8), fb);
+    if (res) unpack8t<F16>(*reinterpret_cast<const uint4*>(res + i * 8), fr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) fn[e] = fmaf(fn[e], 1.f + fg[e], fb[e]) + (res ? fr[e] : 0.f);
-    *reinterpret_cast<uint4*>(y + i * 8) = pack8(fn);
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8t<F16>(fn);
   }
 }
 
@@ -194,23 +169,25 @@ __global__ void vec_mul_group_kernel(const float* a, const float* b, float* out,
 }
 
 // ---- layout / boundary kernels --------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int C,
                                                            long long HW, int Cpad, float mul, float add, long long total) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long n = i / HW, p = i - n * HW;
     const float* xi = x + n * C * HW + p;
     uint16_t* yo = y + i * Cpad;
-    for (int c = 0; c < Cpad; ++c) yo[c] = c < C ? f2bf(xi[(long long)c * HW] * mul + add) : (uint16_t)0;
+    for (int c = 0; c < Cpad; ++c) yo[c] = c < C ? f2h16<F16>(xi[(long long)c * HW] * mul + add) : (uint16_t)0;
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ x, int is_f32, float* __restrict__ out,
                                                            int C, long long HW, int ld, float mul, float add,
                                                            long long total) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long n = i / HW, p = i - n * HW;
     for (int c = 0; c < C; ++c) {
-      float v = is_f32 ? reinterpret_cast<const float*>(x)[i * ld + c] : bf2f(reinterpret_cast<const uint16_t*>(x)[i * ld + c]);
+      float v = is_f32 ? reinterpret_cast<const float*>(x)[i * ld + c] : Act<F16>::one(reinterpret_cast<const uint16_t*>(x)[i * ld + c]);
       out[(n * C + c) * HW + p] = v * mul + add;
     }
   }
@@ -234,6 +211,7 @@ __device__ __forceinline__ void cubic_taps(int dst, float scale, int in_size, in
 }
 
 // img [N,C,H,W] fp32 -> (bicubic to RH x RW) -> reflect pad right/bottom -> v*mul+add -> y bf16 [N,RH+PH,RW+PW,Cpad]
+template <bool F16>
 __global__ __launch_bounds__(256) void image_resize_pad_kernel(const float* __restrict__ img, uint16_t* __restrict__ y, int C,
                                                                int H, int W, int RH, int RW, int PH, int PW, int Cpad,
                                                                float mul, float add, long long total) {
@@ -248,7 +226,7 @@ __global__ __launch_bounds__(256) void image_resize_pad_kernel(const float* __re
     const float* base = img + (long long)n * C * H * W;
     uint16_t* yo = y + i * Cpad;
     if (!resize) {
-      for (int c = 0; c < Cpad; ++c) yo[c] = c < C ? f2bf(base[((long long)c * H + ry) * W + rx] * mul + add) : (uint16_t)0;
+      for (int c = 0; c < Cpad; ++c) yo[c] = c < C ? f2h16<F16>(base[((long long)c * H + ry) * W + rx] * mul + add) : (uint16_t)0;
       continue;
     }
     int iy[4], ix[4];
@@ -265,13 +243,14 @@ __global__ __launch_bounds__(256) void image_resize_pad_kernel(const float* __re
           v += wy[a] * (wx[0] * row[ix[0]] + wx[1] * row[ix[1]] + wx[2] * row[ix[2]] + wx[3] * row[ix[3]]);
         }
       }
-      yo[c] = c < C ? f2bf(v * mul + add) : (uint16_t)0;
+      yo[c] = c < C ? f2h16<F16>(v * mul + add) : (uint16_t)0;
     }
   }
 }
 
 // x NHWC (bf16 | fp32) [N,XH,XW,ld] -> v*mul+add -> crop [0:CH, 0:CW] -> bicubic to OH x OW -> optional
 // mul(255).round().clamp(0,255).div(255) -> out fp32 [N,C,OH,OW]
+template <bool F16>
 __global__ __launch_bounds__(256) void image_unpad_resize_kernel(const void* __restrict__ x, int is_f32, float* __restrict__ out,
                                                                  int C, int XH, int XW, int ld, int CH, int CW, int OH, int OW,
                                                                  float mul, float add, int quantize, long long total) {
@@ -292,7 +271,7 @@ __global__ __launch_bounds__(256) void image_unpad_resize_kernel(const void* __r
         float rowv = 0.f;
         for (int b = 0; b < taps; ++b) {
           const long long e = (nb + (long long)iy[a] * XW + ix[b]) * ld + c;
-          const float t = is_f32 ? reinterpret_cast<const float*>(x)[e] : bf2f(reinterpret_cast<const uint16_t*>(x)[e]);
+          const float t = is_f32 ? reinterpret_cast<const float*>(x)[e] : Act<F16>::one(reinterpret_cast<const uint16_t*>(x)[e]);
           rowv += wx[b] * (t * mul + add);
         }
         v += wy[a] * rowv;
@@ -303,6 +282,7 @@ __global__ __launch_bounds__(256) void image_unpad_resize_kernel(const void* __r
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void vae_sample_kernel(const float* __restrict__ mom, int ld, const float* __restrict__ noise,
                                                          float* __restrict__ z, uint16_t* __restrict__ zb, long long HW,
                                                          int Clat, int Cpad, float scale, long long total) {
@@ -316,11 +296,12 @@ __global__ __launch_bounds__(256) void vae_sample_kernel(const float* __restrict
         v = (mean + expf(0.5f * lv) * noise[(n * Clat + c) * HW + p]) * scale;
       }
       z[i * Cpad + c] = v;
-      zb[i * Cpad + c] = f2bf(v);
+      zb[i * Cpad + c] = f2h16<F16>(v);
     }
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ z0, const float* __restrict__ noise,
                                                         float* __restrict__ zt, uint16_t* __restrict__ zb, long long HW,
                                                         int Clat, int Cpad, float sa, float sb, long long total) {
@@ -329,11 +310,12 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict_
     for (int c = 0; c < Cpad; ++c) {
       const float v = c < Clat ? sa * z0[i * Cpad + c] + sb * noise[(n * Clat + c) * HW + p] : 0.f;
       zt[i * Cpad + c] = v;
-      zb[i * Cpad + c] = f2bf(v);
+      zb[i * Cpad + c] = f2h16<F16>(v);
     }
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void ddim_step_kernel(float* __restrict__ zt, const float* __restrict__ eps, int ld_eps,
                                                         uint16_t* __restrict__ zb, int Clat, int Cpad, float cx, float ce,
                                                         long long total) {
@@ -341,15 +323,16 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(float* __restrict__ zt, 
     for (int c = 0; c < Cpad; ++c) {
       const float v = c < Clat ? cx * zt[i * Cpad + c] + ce * eps[i * ld_eps + c] : 0.f;
       zt[i * Cpad + c] = v;
-      zb[i * Cpad + c] = f2bf(v);
+      zb[i * Cpad + c] = f2h16<F16>(v);
     }
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, int ld, uint16_t* __restrict__ y, int C,
                                                           int Cpad, float mul, long long total) {
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
-    for (int c = 0; c < Cpad; ++c) y[i * Cpad + c] = c < C ? f2bf(x[i * ld + c] * mul) : (uint16_t)0;
+    for (int c = 0; c < Cpad; ++c) y[i * Cpad + c] = c < C ? f2h16<F16>(x[i * ld + c] * mul) : (uint16_t)0;
 }
 
 inline int nblocks(long long total) { return (int)std::min<long long>((total + 255) / 256, 8192); }
@@ -359,64 +342,51 @@ inline int nblocks(long long total) { return (int)std::min<long long>((total + 2
 extern "C" {
 
 int ur_dwconv3x3_nhwc(const void* x, const float* w9c, const float* bias, void* y, int N, int H, int W, int C, int gate,
-                      ur_stream_t stream) {
+                      int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(x && w9c && bias && y, "null pointer");
   UR_REQUIRE(C % (gate ? 16 : 8) == 0, "C must be a multiple of 8 (16 with gate)");
   hipStream_t s = (hipStream_t)stream;
   const double elems = (double)N * H * W * C;
   ur::ProfScope prof("dwconv3x3", 18.0 * elems, 2.0 * elems * (gate ? 1.5 : 2.0), s);
   const long long total = (long long)N * H * W * ((gate ? C / 2 : C) / 8);
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(nblocks(total)), dim3(256), 0, s, (const uint16_t*)x, w9c, bias, (uint16_t*)y, N,
-                     H, W, C, gate);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(dwconv3x3_kernel<F16>, dim3(nblocks(total)), dim3(256), 0, s, (const uint16_t*)x, w9c, bias, (uint16_t*)y, N,
+                     H, W, C, gate));
   return ur::check_launch("ur_dwconv3x3_nhwc");
 }
 
-int ur_avgpool_hw(const void* x, float* out, int N, int HW, int C, ur_stream_t stream) {
-  UR_REQUIRE(x && out && C % 8 == 0, "bad args");
-  hipStream_t s = (hipStream_t)stream;
-  ur::ProfScope prof("avgpool", 0.0, 2.0 * N * (double)HW * C, s);
-  ur::zero_async(out, (size_t)N * C * sizeof(float), s);
-  const int cv = C / 8;
-  int cvs = cv < 32 ? cv : 32;
-  while (cv % cvs) --cvs;
-  const int slabs = cv / cvs, R = 256 / cvs;
-  long long want = std::max<long long>(1, 2048 / ((long long)N * slabs));
-  int chunks = (int)std::min<long long>(want, std::max(1, HW / (4 * R)));
-  const int ppb = (HW + chunks - 1) / chunks;
-  chunks = (HW + ppb - 1) / ppb;
-  hipLaunchKernelGGL(avgpool_kernel, dim3(chunks, N, slabs), dim3(256), 0, s, (const uint16_t*)x, out, HW, C, ppb, 1.0f / HW, cvs);
-  return ur::check_launch("ur_avgpool_hw");
-}
-
 int ur_scale_channels(const void* x, const float* sc, const void* residual, void* y, int N, int HW, int C,
-                      ur_stream_t stream) {
+                      int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(x && sc && y && C % 8 == 0, "bad args");
   hipStream_t s = (hipStream_t)stream;
   const long long totalv = (long long)N * HW * (C / 8);
   ur::ProfScope prof("elementwise", 0.0, (residual ? 6.0 : 4.0) * totalv * 8.0, s);
-  hipLaunchKernelGGL(scale_channels_kernel, dim3(nblocks(totalv)), dim3(256), 0, s, (const uint16_t*)x, sc,
-                     (const uint16_t*)residual, (uint16_t*)y, (long long)HW * (C / 8), C / 8, totalv);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(scale_channels_kernel<F16>, dim3(nblocks(totalv)), dim3(256), 0, s, (const uint16_t*)x, sc,
+                     (const uint16_t*)residual, (uint16_t*)y, (long long)HW * (C / 8), C / 8, totalv));
   return ur::check_launch("ur_scale_channels");
 }
 
-int ur_axpy_channels(const void* a, const void* b, const float* sc, void* y, long long rows, int C, ur_stream_t stream) {
+int ur_axpy_channels(const void* a, const void* b, const float* sc, void* y, long long rows, int C, int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(a && b && sc && y && C % 8 == 0, "bad args");
   hipStream_t s = (hipStream_t)stream;
   const long long totalv = rows * (C / 8);
   ur::ProfScope prof("elementwise", 0.0, 6.0 * totalv * 8.0, s);
-  hipLaunchKernelGGL(axpy_channels_kernel, dim3(nblocks(totalv)), dim3(256), 0, s, (const uint16_t*)a, (const uint16_t*)b, sc,
-                     (uint16_t*)y, C / 8, totalv);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(axpy_channels_kernel<F16>, dim3(nblocks(totalv)), dim3(256), 0, s, (const uint16_t*)a, (const uint16_t*)b, sc,
+                     (uint16_t*)y, C / 8, totalv));
   return ur::check_launch("ur_axpy_channels");
 }
 
 int ur_spade_modulate(const void* n, const void* gb, int ldgb, const void* residual, void* y, long long rows, int C,
-                      ur_stream_t stream) {
+                      int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(n && gb && y && C % 8 == 0 && ldgb % 8 == 0 && ldgb >= 2 * C && rows > 0, "bad args");
   hipStream_t s = (hipStream_t)stream;
   const long long totalv = rows * (C / 8);
   ur::ProfScope prof("elementwise", 0.0, (residual ? 10.0 : 8.0) * totalv * 8.0, s);
-  hipLaunchKernelGGL(spade_modulate_kernel, dim3(nblocks(totalv)), dim3(256), 0, s, (const uint16_t*)n, (const uint16_t*)gb, ldgb,
-                     (const uint16_t*)residual, (uint16_t*)y, C / 8, totalv);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(spade_modulate_kernel<F16>, dim3(nblocks(totalv)), dim3(256), 0, s, (const uint16_t*)n, (const uint16_t*)gb, ldgb,
+                     (const uint16_t*)residual, (uint16_t*)y, C / 8, totalv));
   return ur::check_launch("ur_spade_modulate");
 }
 
@@ -441,81 +411,90 @@ int ur_vec_mul_group(const float* a, const float* b, float* out, int N, int C, i
   return ur::check_launch("ur_vec_mul_group");
 }
 
-int ur_nchw_f32_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, ur_stream_t stream) {
+int ur_nchw_f32_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(x && y && Cpad >= C, "bad args");
   const long long total = (long long)N * H * W;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, C,
-                     (long long)H * W, Cpad, 1.f, 0.f, total);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<F16>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, C,
+                     (long long)H * W, Cpad, 1.f, 0.f, total));
   return ur::check_launch("ur_nchw_f32_to_nhwc");
 }
 
-int ur_image_to_nhwc(const float* img, void* y, int N, int C, int H, int W, int Cpad, ur_stream_t stream) {
+int ur_image_to_nhwc(const float* img, void* y, int N, int C, int H, int W, int Cpad, int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(img && y && Cpad >= C, "bad args");
   const long long total = (long long)N * H * W;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, img, (uint16_t*)y, C,
-                     (long long)H * W, Cpad, 2.f, -1.f, total);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<F16>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, img, (uint16_t*)y, C,
+                     (long long)H * W, Cpad, 2.f, -1.f, total));
   return ur::check_launch("ur_image_to_nhwc");
 }
 
 int ur_nhwc_to_nchw_f32(const void* x, int x_is_f32, float* out, int N, int C, int H, int W, int ld, float mul, float add,
-                        ur_stream_t stream) {
+                        int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(x && out && ld >= C, "bad args");
   const long long total = (long long)N * H * W;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, x_is_f32, out, C,
-                     (long long)H * W, ld, mul, add, total);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<F16>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, x_is_f32, out, C,
+                     (long long)H * W, ld, mul, add, total));
   return ur::check_launch("ur_nhwc_to_nchw_f32");
 }
 
 int ur_image_resize_pad_nhwc(const float* img, void* y, int N, int C, int H, int W, int RH, int RW, int PH, int PW, int Cpad,
-                             float mul, float add, ur_stream_t stream) {
+                             float mul, float add, int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(img && y && Cpad >= C && N > 0 && H > 0 && W > 0 && RH > 0 && RW > 0, "bad args");
   UR_REQUIRE(PH >= 0 && PW >= 0 && PH < RH && PW < RW, "reflect padding must be smaller than the image");
   const long long total = (long long)N * (RH + PH) * (RW + PW);
-  hipLaunchKernelGGL(image_resize_pad_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, img, (uint16_t*)y, C, H, W,
-                     RH, RW, PH, PW, Cpad, mul, add, total);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(image_resize_pad_kernel<F16>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, img, (uint16_t*)y, C, H, W,
+                     RH, RW, PH, PW, Cpad, mul, add, total));
   return ur::check_launch("ur_image_resize_pad_nhwc");
 }
 
 int ur_image_unpad_resize_nchw(const void* x, int x_is_f32, float* out, int N, int C, int XH, int XW, int ld, int CH, int CW,
-                               int OH, int OW, float mul, float add, int quantize, ur_stream_t stream) {
+                               int OH, int OW, float mul, float add, int quantize, int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(x && out && ld >= C && N > 0 && OH > 0 && OW > 0, "bad args");
   UR_REQUIRE(CH > 0 && CW > 0 && CH <= XH && CW <= XW, "crop window must lie inside the input");
   const long long total = (long long)N * OH * OW;
-  hipLaunchKernelGGL(image_unpad_resize_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, x_is_f32, out, C, XH, XW,
-                     ld, CH, CW, OH, OW, mul, add, quantize, total);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(image_unpad_resize_kernel<F16>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, x_is_f32, out, C, XH, XW,
+                     ld, CH, CW, OH, OW, mul, add, quantize, total));
   return ur::check_launch("ur_image_unpad_resize_nchw");
 }
 
-int ur_vae_sample(const float* moments, int ld, const float* noise_nchw, float* z_nhwc, void* z_bf16, int N, int HW,
-                  int Clat, int Cpad, float scale, ur_stream_t stream) {
-  UR_REQUIRE(moments && noise_nchw && z_nhwc && z_bf16 && ld >= 2 * Clat && Cpad >= Clat, "bad args");
+int ur_vae_sample(const float* moments, int ld, const float* noise_nchw, float* z_nhwc, void* z_16, int N, int HW,
+                  int Clat, int Cpad, float scale, int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
+  UR_REQUIRE(moments && noise_nchw && z_nhwc && z_16 && ld >= 2 * Clat && Cpad >= Clat, "bad args");
   const long long total = (long long)N * HW;
-  hipLaunchKernelGGL(vae_sample_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, moments, ld, noise_nchw,
-                     z_nhwc, (uint16_t*)z_bf16, (long long)HW, Clat, Cpad, scale, total);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(vae_sample_kernel<F16>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, moments, ld, noise_nchw,
+                     z_nhwc, (uint16_t*)z_16, (long long)HW, Clat, Cpad, scale, total));
   return ur::check_launch("ur_vae_sample");
 }
 
-int ur_add_noise(const float* z0, const float* noise_nchw, float* zt, void* zt_bf16, int N, int HW, int Clat, int Cpad,
-                 float sa, float sb, ur_stream_t stream) {
-  UR_REQUIRE(z0 && noise_nchw && zt && zt_bf16, "null pointer");
+int ur_add_noise(const float* z0, const float* noise_nchw, float* zt, void* zt_16, int N, int HW, int Clat, int Cpad,
+                 float sa, float sb, int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
+  UR_REQUIRE(z0 && noise_nchw && zt && zt_16, "null pointer");
   const long long total = (long long)N * HW;
-  hipLaunchKernelGGL(add_noise_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, z0, noise_nchw, zt,
-                     (uint16_t*)zt_bf16, (long long)HW, Clat, Cpad, sa, sb, total);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(add_noise_kernel<F16>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, z0, noise_nchw, zt,
+                     (uint16_t*)zt_16, (long long)HW, Clat, Cpad, sa, sb, total));
   return ur::check_launch("ur_add_noise");
 }
 
-int ur_ddim_step(float* zt, const float* eps, int ld_eps, void* zt_bf16, long long M, int Clat, int Cpad, float c_x,
-                 float c_e, ur_stream_t stream) {
-  UR_REQUIRE(zt && eps && zt_bf16 && ld_eps >= Clat, "bad args");
-  hipLaunchKernelGGL(ddim_step_kernel, dim3(nblocks(M)), dim3(256), 0, (hipStream_t)stream, zt, eps, ld_eps,
-                     (uint16_t*)zt_bf16, Clat, Cpad, c_x, c_e, M);
+int ur_ddim_step(float* zt, const float* eps, int ld_eps, void* zt_16, long long M, int Clat, int Cpad, float c_x,
+                 float c_e, int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
+  UR_REQUIRE(zt && eps && zt_16 && ld_eps >= Clat, "bad args");
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(ddim_step_kernel<F16>, dim3(nblocks(M)), dim3(256), 0, (hipStream_t)stream, zt, eps, ld_eps,
+                     (uint16_t*)zt_16, Clat, Cpad, c_x, c_e, M));
   return ur::check_launch("ur_ddim_step");
 }
 
-int ur_f32_to_bf16_scaled(const float* x, int ld, void* y, long long M, int C, int Cpad, float mul, ur_stream_t stream) {
+int ur_f32_to_bf16_scaled(const float* x, int ld, void* y, long long M, int C, int Cpad, float mul, int dtype, ur_stream_t stream) {
+  UR_REQUIRE_DT(dtype);
   UR_REQUIRE(x && y && ld >= C && Cpad >= C, "bad args");
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(nblocks(M)), dim3(256), 0, (hipStream_t)stream, x, ld, (uint16_t*)y, C, Cpad,
-                     mul, M);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(f32_to_bf16_kernel<F16>, dim3(nblocks(M)), dim3(256), 0, (hipStream_t)stream, x, ld, (uint16_t*)y, C, Cpad,
+                     mul, M));
   return ur::check_launch("ur_f32_to_bf16_scaled");
 }
 

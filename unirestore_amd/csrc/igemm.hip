@@ -14,26 +14,64 @@
 //   * block id -> tile map is XCD-aware (blocks that share an activation tile land on one XCD's L2).
 #include "igemm_impl.h"
 
-namespace urk {   // launcher instantiations live in igemm_v1a/v1b/v2/halo.hip (parallel compilation)
-int v1_128x128(void* kp, hipStream_t s);
-int v1_128x160(void* kp, hipStream_t s);
-int v1_128x64(void* kp, hipStream_t s);
-int v1_256x32(void* kp, hipStream_t s);
-int v1_64x64(void* kp, hipStream_t s);
-int v2_256x32(void* kp, hipStream_t s);
-int v2_128x64(void* kp, hipStream_t s);
-int v2_256x160(void* kp, hipStream_t s);
-int v2_256x128(void* kp, hipStream_t s);
-int gemm_256x256(void* kp, hipStream_t s);
-int gemm_256x320_pair(void* kp, hipStream_t s);
-int g1_128x128(void* kp, hipStream_t s);
-int g1_128x160(void* kp, hipStream_t s);
-int g1_128x64(void* kp, hipStream_t s);
-int g1_64x64(void* kp, hipStream_t s);
-int halo_8x32_160(void* kp, hipStream_t s);
-int halo_8x32_128(void* kp, hipStream_t s);
-int himg_16x16(void* kp, hipStream_t s);
-int himg_8x8x4(void* kp, hipStream_t s);
+namespace urk {   // launcher instantiations live in igemm_v1a/v1b/v2/halo/g1.hip, one object per 16-bit type (parallel compilation)
+int v1_128x128_bf16(void* kp, hipStream_t s);
+int v1_128x128_f16(void* kp, hipStream_t s);
+static inline int v1_128x128(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? v1_128x128_f16(kp, s) : v1_128x128_bf16(kp, s); }
+int v1_128x160_bf16(void* kp, hipStream_t s);
+int v1_128x160_f16(void* kp, hipStream_t s);
+static inline int v1_128x160(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? v1_128x160_f16(kp, s) : v1_128x160_bf16(kp, s); }
+int v1_128x64_bf16(void* kp, hipStream_t s);
+int v1_128x64_f16(void* kp, hipStream_t s);
+static inline int v1_128x64(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? v1_128x64_f16(kp, s) : v1_128x64_bf16(kp, s); }
+int v1_256x32_bf16(void* kp, hipStream_t s);
+int v1_256x32_f16(void* kp, hipStream_t s);
+static inline int v1_256x32(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? v1_256x32_f16(kp, s) : v1_256x32_bf16(kp, s); }
+int v1_64x64_bf16(void* kp, hipStream_t s);
+int v1_64x64_f16(void* kp, hipStream_t s);
+static inline int v1_64x64(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? v1_64x64_f16(kp, s) : v1_64x64_bf16(kp, s); }
+int v2_256x32_bf16(void* kp, hipStream_t s);
+int v2_256x32_f16(void* kp, hipStream_t s);
+static inline int v2_256x32(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? v2_256x32_f16(kp, s) : v2_256x32_bf16(kp, s); }
+int v2_128x64_bf16(void* kp, hipStream_t s);
+int v2_128x64_f16(void* kp, hipStream_t s);
+static inline int v2_128x64(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? v2_128x64_f16(kp, s) : v2_128x64_bf16(kp, s); }
+int v2_256x160_bf16(void* kp, hipStream_t s);
+int v2_256x160_f16(void* kp, hipStream_t s);
+static inline int v2_256x160(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? v2_256x160_f16(kp, s) : v2_256x160_bf16(kp, s); }
+int v2_256x128_bf16(void* kp, hipStream_t s);
+int v2_256x128_f16(void* kp, hipStream_t s);
+static inline int v2_256x128(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? v2_256x128_f16(kp, s) : v2_256x128_bf16(kp, s); }
+int gemm_256x256_bf16(void* kp, hipStream_t s);
+int gemm_256x256_f16(void* kp, hipStream_t s);
+static inline int gemm_256x256(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? gemm_256x256_f16(kp, s) : gemm_256x256_bf16(kp, s); }
+int gemm_256x320_pair_bf16(void* kp, hipStream_t s);
+int gemm_256x320_pair_f16(void* kp, hipStream_t s);
+static inline int gemm_256x320_pair(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? gemm_256x320_pair_f16(kp, s) : gemm_256x320_pair_bf16(kp, s); }
+int g1_128x128_bf16(void* kp, hipStream_t s);
+int g1_128x128_f16(void* kp, hipStream_t s);
+static inline int g1_128x128(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? g1_128x128_f16(kp, s) : g1_128x128_bf16(kp, s); }
+int g1_128x160_bf16(void* kp, hipStream_t s);
+int g1_128x160_f16(void* kp, hipStream_t s);
+static inline int g1_128x160(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? g1_128x160_f16(kp, s) : g1_128x160_bf16(kp, s); }
+int g1_128x64_bf16(void* kp, hipStream_t s);
+int g1_128x64_f16(void* kp, hipStream_t s);
+static inline int g1_128x64(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? g1_128x64_f16(kp, s) : g1_128x64_bf16(kp, s); }
+int g1_64x64_bf16(void* kp, hipStream_t s);
+int g1_64x64_f16(void* kp, hipStream_t s);
+static inline int g1_64x64(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? g1_64x64_f16(kp, s) : g1_64x64_bf16(kp, s); }
+int halo_8x32_160_bf16(void* kp, hipStream_t s);
+int halo_8x32_160_f16(void* kp, hipStream_t s);
+static inline int halo_8x32_160(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? halo_8x32_160_f16(kp, s) : halo_8x32_160_bf16(kp, s); }
+int halo_8x32_128_bf16(void* kp, hipStream_t s);
+int halo_8x32_128_f16(void* kp, hipStream_t s);
+static inline int halo_8x32_128(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? halo_8x32_128_f16(kp, s) : halo_8x32_128_bf16(kp, s); }
+int himg_16x16_bf16(void* kp, hipStream_t s);
+int himg_16x16_f16(void* kp, hipStream_t s);
+static inline int himg_16x16(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? himg_16x16_f16(kp, s) : himg_16x16_bf16(kp, s); }
+int himg_8x8x4_bf16(void* kp, hipStream_t s);
+int himg_8x8x4_f16(void* kp, hipStream_t s);
+static inline int himg_8x8x4(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? himg_8x8x4_f16(kp, s) : himg_8x8x4_bf16(kp, s); }
 }  // namespace urk
 
 namespace {
@@ -126,31 +164,31 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
 
 }  // namespace
 
-static int conv_impl(const ur_conv_desc* d, ur_stream_t stream, int dry, int* plan_tn) {
+static int conv_impl(const ur_conv_desc* d, ur_stream_t stream, int dry, ur_conv_plan* plan) {
   UR_REQUIRE(d && d->x && d->w, "null x/w");
   UR_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3), "only 1x1 and 3x3 kernels");
   UR_REQUIRE(d->C1 > 0 && d->C1 % 8 == 0 && d->C2 % 8 == 0 && d->ldx % 8 == 0, "Cin/ldx must be multiples of 8");
   UR_REQUIRE(d->C2 == 0 || (d->x2 && d->ldx2 % 8 == 0), "virtual concat needs x2");
   UR_REQUIRE(d->Cout > 0 && d->Cout % 4 == 0 && d->ldw % 8 == 0, "Cout%4, ldw%8");
   UR_REQUIRE(d->nbatch >= 1 && d->stride >= 1 && d->OH > 0 && d->OW > 0, "bad dims");
-  UR_REQUIRE(d->y || d->yt || d->colsum, "no output requested");
+  UR_REQUIRE(d->y || d->yt || d->gn_part, "no output requested");
+  UR_REQUIRE_DT(d->dtype);
   const bool pair = d->act == UR_ACT_GEGLU || d->act == UR_ACT_GATE;
   UR_REQUIRE(!pair || d->Cout % 64 == 0, "pair activations need Cout%64==0 (32-row a|g interleave)");
   UR_REQUIRE(!d->y || (d->out_f32 ? d->ldy % 4 == 0 : d->ldy % 4 == 0), "ldy%4");
   UR_REQUIRE(!d->residual || d->ldr % 4 == 0, "ldr%4");
   UR_REQUIRE(!d->yt || (d->t_rows > 0 && d->n_split % 4 == 0 && !pair), "bad transposed-output spec");
-  UR_REQUIRE(!d->colsum || ((d->OH * d->OW) % 32 == 0), "colsum needs OH*OW % 32 == 0");
 
   ConvK k;
   k.x = (const uint16_t*)d->x; k.x2 = (const uint16_t*)d->x2; k.w = (const uint16_t*)d->w; k.bias = d->bias;
-  k.res = (const uint16_t*)d->residual; k.y = d->y; k.yt = (uint16_t*)d->yt; k.colsum = d->colsum;
+  k.res = (const uint16_t*)d->residual; k.y = d->y; k.yt = (uint16_t*)d->yt;
   k.ws = d->workspace; k.ws_bytes_ = d->workspace_bytes;
   k.N = d->N; k.H = d->H; k.W = d->W; k.C1 = d->C1; k.ldx = d->ldx; k.C2 = d->C2; k.ldx2 = d->ldx2;
   k.Cin = d->C1 + d->C2; k.Cout = d->Cout; k.ldw = d->ldw; k.ldy = d->ldy; k.ldr = d->ldr;
   k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad_t = d->pad_t; k.pad_l = d->pad_l;
   k.OH = d->OH; k.OW = d->OW; k.OHW = d->OH * d->OW; k.ups = d->upsample2x; k.act = d->act; k.out_f32 = d->out_f32;
   k.n_split = d->yt ? d->n_split : d->Cout; k.t_rows = d->t_rows; k.t_ld = d->t_ld;
-  k.out_scale = d->out_scale; k.colsum_scale = d->colsum_scale;
+  k.out_scale = d->out_scale;
   k.M = d->N * d->OH * d->OW; k.Ktot = d->KH * d->KW * k.Cin; k.nk = (k.Ktot + 63) / 64; k.nbatch = d->nbatch;
   k.bs_x = d->bs_x; k.bs_x2 = d->bs_x2; k.bs_w = d->bs_w; k.bs_bias = d->bs_bias; k.bs_y = d->bs_y; k.bs_r = d->bs_r; k.bias_img = d->bias_img_stride;
   UR_REQUIRE(k.M > 0, "empty problem");
@@ -160,15 +198,16 @@ static int conv_impl(const ur_conv_desc* d, ur_stream_t stream, int dry, int* pl
 
   k.kcm = d->k_chunk_major;
   UR_REQUIRE(!k.kcm || (k.Cin % 64 == 0 && d->C1 % 64 == 0), "k_chunk_major needs C1 and C1+C2 to be multiples of 64");
-  k.gn_stats = d->gn_stats;
+  k.gn_part = d->gn_part; k.gn_ab = d->gn_ab; k.gn_silu = d->gn_silu; k.f16 = d->dtype == UR_DT_F16; k.gn_fused = 0; k.gn_parts = 0; k.prologue_ok = 0;
   k.dry = dry; k.plan_tn = 0; k.ln_parts = d->ln_parts;
   k.row_stats = d->row_stats; k.ln_stats = d->ln_stats; k.ln_colsum = d->ln_colsum; k.ln_eps = d->ln_eps; k.ln_dim = d->ln_dim;
   UR_REQUIRE(!d->ln_stats || (d->ln_colsum && d->ln_dim > 0), "ln_stats needs ln_colsum / ln_dim");
   // feature combinations the specialised epilogues cover (each is one compiled instance; see epi_frag_pass)
   UR_REQUIRE(!(d->bias_img_stride && (pair || d->ln_stats || d->yt)), "per-image bias rows do not combine with pair activations / LayerNorm folding / transposed columns");
-  k.staged_ok_ = d->y && !d->out_f32 && !d->colsum && ((d->ldy | d->bs_y) & 7) == 0 &&
+  // staged (LDS-tiled, 16-byte row stores) epilogue: 16-bit y with aligned rows, or no y at all (statistics-only launch)
+  k.staged_ok_ = (d->y ? (!d->out_f32 && ((d->ldy | d->bs_y) & 7) == 0) : d->gn_part != nullptr) &&
                  (!d->residual || ((d->ldr | d->bs_r) & 7) == 0);
-  UR_REQUIRE(!d->gn_stats || (d->y && !d->out_f32 && !d->yt), "gn_stats needs a plain bf16 output");
+  UR_REQUIRE(!d->gn_part || (!d->out_f32 && !d->yt), "gn_part needs a plain 16-bit output (or none)");
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * k.M * (double)k.Cout * k.Ktot * k.nbatch;
   const double bytes = 2.0 * ((double)k.M * k.Cin + (double)k.Cout * k.Ktot + (double)k.M * k.Cout) * k.nbatch;
@@ -183,29 +222,69 @@ static int conv_impl(const ur_conv_desc* d, ur_stream_t stream, int dry, int* pl
   }
   if (dry) {
     const int rc0 = dispatch_conv(k, s, pair);
-    if (plan_tn) *plan_tn = k.plan_tn;
+    if (plan) {
+      plan->row_stat_parts = d->row_stats ? k.plan_tn : 0;
+      plan->gn_parts = k.gn_parts; plan->gn_fused = k.gn_fused; plan->prologue_ok = k.prologue_ok;
+    }
     return rc0;
+  }
+  if (!d->y && d->gn_part) {            // statistics-only launch: only where the epilogue itself produces the partials
+    k.dry = 1;
+    const int rc0 = dispatch_conv(k, s, pair);
+    if (rc0 != UR_OK) return rc0;
+    if (!k.gn_fused || k.splitk > 1) return ur::fail(UR_E_UNSUPPORTED, "ur_conv2d_nhwc: y == NULL needs a launch whose epilogue writes gn_part (see ur_conv2d_plan)");
+    k.dry = 0;
+  }
+  if (d->gn_ab) {
+    k.dry = 1;
+    const int rc0 = dispatch_conv(k, s, pair);
+    if (rc0 != UR_OK) return rc0;
+    if (!k.prologue_ok) return ur::fail(UR_E_UNSUPPORTED, "ur_conv2d_nhwc: gn_ab is not supported by this launch (see ur_conv2d_plan.prologue_ok)");
+    k.dry = 0;
   }
   ur::ProfScope prof(fam, flops, bytes, s);
   UR_REQUIRE(!(d->row_stats || d->ln_stats) || (k.staged_ok_ && k.nbatch == 1 && !d->yt == !d->yt), "row_stats / ln fusion need a bf16 staged output");
   const int rc = dispatch_conv(k, s, pair);
   if (rc != UR_OK) return rc;
-  if (k.gn_stats && !k.gn_fused) {   // this launch could not fuse the statistics: one extra pass over the output
+  if (k.gn_part && !k.gn_fused) {   // this launch could not fuse the statistics: one extra pass over the output
     const int ctot = (pair ? k.Cout / 2 : k.Cout) * k.nbatch;
-    UR_REQUIRE(k.ldy == ctot, "gn_stats fallback needs a dense output (ldy == channels)");
-    return ur::gn_stats_launch(k.y, k.gn_stats, k.N, k.OHW, ctot, s);
+    UR_REQUIRE(k.y && k.ldy == ctot, "gn_part fallback needs a dense output (ldy == channels)");
+    return ur::gn_stats_launch(k.y, k.gn_part, k.N, k.OHW, ctot, d->dtype, s);
   }
   return UR_OK;
 }
 
 extern "C" int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream) { return conv_impl(d, stream, 0, nullptr); }
 
-// Number of N tiles the launch of `d` will use = number of partial row-sum planes it writes into d->row_stats
-// ([parts][M][2] fp32).  Negative on error.  (The partial layout keeps the producer free of atomics.)
-extern "C" int ur_conv2d_row_stat_parts(const ur_conv_desc* d) {
-  int parts = 0;
+// Host-only plan of the launch of `d` (no kernel runs): partial row-sum planes ([parts][M][2] fp32, one per N tile - the
+// partial layout keeps the producer free of atomics), GroupNorm partials per image and who writes them, prologue support.
+extern "C" int ur_conv2d_plan(const ur_conv_desc* d, ur_conv_plan* plan) {
+  UR_REQUIRE(d && plan, "null pointer");
   ur_conv_desc t = *d;
-  if (!t.row_stats) t.row_stats = reinterpret_cast<float*>(16);   // any non-null value: the plan must match the real launch
-  const int rc = conv_impl(&t, nullptr, 1, &parts);
-  return rc == UR_OK ? parts : rc;
+  if (!t.y && !t.yt && !t.gn_part) t.y = reinterpret_cast<void*>(16);    // any non-null value: only the plan is wanted
+  return conv_impl(&t, nullptr, 1, plan);
+}
+
+extern "C" int ur_gemm_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y, long long M, int N, int K,
+                                int ldx, int ldw, int ldy, int ldr, int act, float* workspace, size_t workspace_bytes, int dtype,
+                                ur_stream_t stream) {
+  UR_REQUIRE(M > 0 && M < (1ll << 31), "M out of range");
+  ur_conv_desc d = {};
+  d.x = x; d.w = w; d.bias = bias; d.residual = residual; d.y = y;
+  d.workspace = workspace; d.workspace_bytes = workspace_bytes;
+  d.N = 1; d.H = 1; d.W = (int)M; d.C1 = K; d.ldx = ldx; d.Cout = N; d.ldw = ldw; d.ldy = ldy; d.ldr = ldr;
+  d.KH = d.KW = 1; d.stride = 1; d.OH = 1; d.OW = (int)M; d.act = act; d.out_scale = 1.f; d.nbatch = 1; d.dtype = dtype;
+  return conv_impl(&d, stream, 0, nullptr);
+}
+
+extern "C" int ur_groupconv3x3_nhwc(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cg, int Cog,
+                                    int groups, int act, float* workspace, size_t workspace_bytes, int dtype, ur_stream_t stream) {
+  UR_REQUIRE(groups >= 1 && Cg % 8 == 0 && Cog % 4 == 0, "groups >= 1, Cg % 8 == 0, Cog % 4 == 0");
+  ur_conv_desc d = {};
+  d.x = x; d.w = w; d.bias = bias; d.y = y;
+  d.workspace = workspace; d.workspace_bytes = workspace_bytes;
+  d.N = N; d.H = H; d.W = W; d.C1 = Cg; d.ldx = Cg * groups; d.Cout = Cog; d.ldw = 9 * Cg; d.ldy = Cog * groups;
+  d.KH = d.KW = 3; d.stride = 1; d.pad_t = d.pad_l = 1; d.OH = H; d.OW = W; d.act = act; d.out_scale = 1.f; d.nbatch = groups;
+  d.bs_x = Cg; d.bs_w = (long long)Cog * 9 * Cg; d.bs_bias = Cog; d.bs_y = Cog; d.dtype = dtype;
+  return conv_impl(&d, stream, 0, nullptr);
 }

@@ -2,8 +2,8 @@
 #include "igemm_impl.h"
 
 namespace urk {
-int g1_128x128(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 128, 2, 2, 2, true>(k, s); }
-int g1_128x160(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 160, 4, 1, 2, true>(k, s); }
-int g1_128x64(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 64, 2, 2, 2, true>(k, s); }
-int g1_64x64(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<64, 64, 2, 2, 2, true>(k, s); }
+int URK(g1_128x128)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 128, 2, 2, 2, true>(k, s); }
+int URK(g1_128x160)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 160, 4, 1, 2, true>(k, s); }
+int URK(g1_128x64)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 64, 2, 2, 2, true>(k, s); }
+int URK(g1_64x64)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<64, 64, 2, 2, 2, true>(k, s); }
 }  // namespace urk

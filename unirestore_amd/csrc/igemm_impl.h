@@ -29,16 +29,16 @@ namespace {
 
 struct ConvK {
   const uint16_t* x; const uint16_t* x2; const uint16_t* w; const float* bias; const uint16_t* res;
-  void* y; uint16_t* yt; float* colsum; float* ws; double* gn_stats;
+  void* y; uint16_t* yt; float* ws; float* gn_part; const float* gn_ab;
   float* row_stats; const float* ln_stats; const float* ln_colsum; float ln_eps; int ln_dim, ln_parts;
   int dry, plan_tn;
   int N, H, W, C1, ldx, C2, ldx2, Cin, Cout, ldw, ldy, ldr, KH, KW, stride, pad_t, pad_l, OH, OW, OHW;
   int ups, act, out_f32, n_split, t_rows, t_ld;
-  float out_scale, colsum_scale;
+  float out_scale;
   int M, Ktot, nk, tiles_m, tiles_n, splitk, nk_per_split, nbatch;
   long long bs_x, bs_x2, bs_w, bs_bias, bs_y, bs_r, bias_img;
   size_t ws_bytes_;
-  int dbg, gn_fused, staged_ok_;
+  int dbg, gn_fused, gn_parts, gn_silu, f16, staged_ok_, prologue_ok;
   int patch_tw, patch_m0_unused;   // >0: tile rows are an (BM/patch_tw) x patch_tw pixel patch of one image (halo kernel)
   int kcm;   // 1: K runs (64-channel chunk, tap, channel) - the 9 taps of a chunk are consecutive K tiles (L2 reuse)
 };
@@ -52,28 +52,20 @@ __device__ __forceinline__ int tile_row_to_m(const ConvK& p, int m0, int r) {
 }
 
 // Final stage for 4 consecutive output channels [co, co+4) of pixel row m (values already activated/scaled).
-__device__ __forceinline__ void epi_residual(const ConvK& p, int gb, int m, int co, float v[4]) {
-  if (p.res) {
-    const uint16_t* r = p.res + gb * p.bs_r + (long long)m * p.ldr + co;
-    uint2 rv = *reinterpret_cast<const uint2*>(r);
-    v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-    v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-  }
-}
-
+template <bool F16>
 __device__ __forceinline__ void epi_store(const ConvK& p, int gb, int m, int co, float v[4]) {
   if (p.res) {
     const uint16_t* r = p.res + gb * p.bs_r + (long long)m * p.ldr + co;
     uint2 rv = *reinterpret_cast<const uint2*>(r);
-    v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-    v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+    v[0] += Act<F16>::lo(rv.x); v[1] += Act<F16>::hi(rv.x);
+    v[2] += Act<F16>::lo(rv.y); v[3] += Act<F16>::hi(rv.y);
   }
   if (p.yt && co >= p.n_split) {
     int b = m / p.t_rows, t = m - b * p.t_rows;
     int cw = p.Cout - p.n_split;
     uint16_t* o = p.yt + ((long long)b * cw + (co - p.n_split)) * p.t_ld + t;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[(long long)e * p.t_ld] = f2bf(v[e]);
+    for (int e = 0; e < 4; ++e) o[(long long)e * p.t_ld] = f2h16<F16>(v[e]);
     return;
   }
   if (!p.y) return;
@@ -82,7 +74,7 @@ __device__ __forceinline__ void epi_store(const ConvK& p, int gb, int m, int co,
     *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
     uint16_t* o = reinterpret_cast<uint16_t*>(p.y) + gb * p.bs_y + (long long)m * p.ldy + co;
-    *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+    *reinterpret_cast<uint2*>(o) = make_uint2(Act<F16>::pack2(v[0], v[1]), Act<F16>::pack2(v[2], v[3]));
   }
 }
 
@@ -149,7 +141,7 @@ __device__ __forceinline__ void tile_copy(const ConvK& p, uint16_t* g, long long
 }
 
 // Generic (unstaged) epilogue: fp32 outputs, transposed outputs, fused column sums, odd leading dimensions.
-template <int FM, int FN, int WTM, int WTN>
+template <int FM, int FN, int WTM, int WTN, bool F16>
 __device__ __forceinline__ void igemm_epilogue_direct(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn,
                                                       int lane, int gb) {
   const int fhalf = lane >> 5, mrow = lane & 31;
@@ -174,21 +166,7 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ConvK& p, f32x16 (&a
         }
         int co = co_in;
         if (ok) co = epi_act(p, gb, m, co_in, v, g);
-        if (p.colsum) {  // per-image column sums of the activated output (all 32 lanes share co)
-          int mclamp = min(m, p.M - 1);
-          int img = mclamp / p.OHW;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float s = ok ? v[e] : 0.f;
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-            s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
-            if (mrow == 0 && co_in < p.Cout) {
-              int cw = pair ? p.Cout / 2 : p.Cout;   // colsum is [N][nbatch*cw]: batch index = channel group
-              atomicAdd(p.colsum + ((long long)img * p.nbatch + gb) * cw + co + e, s * p.colsum_scale);
-            }
-          }
-        }
-        if (ok) epi_store(p, gb, m, co, v);
+        if (ok) epi_store<F16>(p, gb, m, co, v);
       }
     }
   }
@@ -203,7 +181,7 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ConvK& p, f32x16 (&a
 // from LDS) -> bf16 into the staged tile.  The feature flags are template parameters (0 = off, 1 = on, 2 = decided at run
 // time): the pass is unrolled FN x 4 x FM times, and with run-time flags every instance carries every feature - measured
 // 2.2 us of instruction-fetch stalls per launch on a cold CU.  The caller picks a lean specialisation once per tile.
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int SROW, int PAIR, int LN, int MULTI, int YT, int ACT>
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int SROW, int PAIR, int LN, int MULTI, int YT, int ACT, bool F16>
 __device__ __forceinline__ void epi_frag_pass(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int c0, int wm, int wn, int lane,
                                               int gb, unsigned char* smem, const float* sbias, const float* scol, const float* srow) {
   const int fhalf = lane >> 5, mrow = lane & 31;
@@ -270,16 +248,16 @@ __device__ __forceinline__ void epi_frag_pass(const ConvK& p, f32x16 (&acc)[FN][
         const int mg = tile_row_to_m(p, m0, lm);
         const bool ok = col_ok && mg < p.M;
         if (yt_ && co >= p.n_split) {                                   // transposed columns (V^T) go out directly
-          if (ok) epi_store(p, gb, mg, co, v);
+          if (ok) epi_store<F16>(p, gb, mg, co, v);
           continue;
         }
         uint2* sp = reinterpret_cast<uint2*>(smem + lm * SROW + lco * 2);
         if (has_res) {
           const uint2 rv = *sp;
-          v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-          v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+          v[0] += Act<F16>::lo(rv.x); v[1] += Act<F16>::hi(rv.x);
+          v[2] += Act<F16>::lo(rv.y); v[3] += Act<F16>::hi(rv.y);
         }
-        if (ok) *sp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        if (ok) *sp = make_uint2(Act<F16>::pack2(v[0], v[1]), Act<F16>::pack2(v[2], v[3]));
       }
     }
   }
@@ -288,7 +266,7 @@ __device__ __forceinline__ void epi_frag_pass(const ConvK& p, f32x16 (&acc)[FN][
 // Staged epilogue body.  CLS 0 = the plain class (no pair activation, no LayerNorm consumer, one bias row per tile, no
 // transposed columns): those features are compiled out, so the executed path is short and contiguous (skipping over
 // feature blocks costs an instruction-cache miss per far branch on a cold CU).  CLS 1 = everything, decided at run time.
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, int CLS, bool PAIRC = false>
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, int CLS, bool PAIRC, bool F16>
 __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
                                                 int gb, unsigned char* smem, bool owner, int nimg_tile_in) {
   // PAIRC: the kernel is only launched for pair activations (host-checked), whose output tile is BN/2 columns wide
@@ -301,8 +279,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
   const int ncols = pair ? BN / 2 : BN;
   const int cmax = min(yt ? p.n_split : (pair ? p.Cout / 2 : p.Cout), c0 + ncols) - c0;     // valid output columns here
   float* sbias = reinterpret_cast<float*>(smem + BM * SROW);                                   // [nimg_tile][BN] floats (GEMM-N order)
-  float* facc = sbias + 4 * BN;                                                                // [2][BN] fused GroupNorm sums
-  float* scol = facc + 2 * BN;                                                                 // [BN] LN fusion: column sums of W*gamma
+  float* scol = sbias + 4 * BN;                                                                 // [BN] LN fusion: column sums of W*gamma
   float* srow = scol + BN;                                                                     // [BM][2] LN fusion: mean, rstd per row
   const int img0 = m0 / p.OHW;
   for (int i = threadIdx.x; i < BN * nimg_tile; i += NT) {
@@ -310,8 +287,6 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
     const long long boff = gb * p.bs_bias + (p.bias_img ? (long long)min(img0 + il, p.N - 1) * p.bias_img : 0);
     sbias[i] = (p.bias && n0 + col < p.Cout) ? p.bias[boff + n0 + col] : 0.f;
   }
-  if (p.gn_fused)
-    for (int i = threadIdx.x; i < 2 * BN; i += NT) facc[i] = 0.f;
   if (ln) {   // this GEMM consumes LayerNorm(x): out = rstd*(acc - mean*s[n]) + t[n]  (t arrives as the bias)
     for (int i = threadIdx.x; i < BN; i += NT) scol[i] = n0 + i < p.Cout ? p.ln_colsum[n0 + i] : 0.f;
     for (int r = threadIdx.x; r < BM; r += NT) {
@@ -337,7 +312,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
     // lean specialisations for the common launches; everything else takes the all-run-time instance
     const bool multi = nimg_tile > 1, hasact = p.act != UR_ACT_NONE;
 #define UR_EPI_PASS(PAIR, LN, MULTI, YT, ACT) \
-    epi_frag_pass<FM, FN, WTM, WTN, BM, BN, SROW, PAIR, LN, MULTI, YT, ACT>(p, acc, m0, n0, c0, wm, wn, lane, gb, smem, sbias, scol, srow)
+    epi_frag_pass<FM, FN, WTM, WTN, BM, BN, SROW, PAIR, LN, MULTI, YT, ACT, F16>(p, acc, m0, n0, c0, wm, wn, lane, gb, smem, sbias, scol, srow)
     if (CLS == 0) { if (hasact) UR_EPI_PASS(0, 0, 0, 0, 1); else UR_EPI_PASS(0, 0, 0, 0, 0); }
     else if (pair) { if (ln) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0); }     // never with multi / yt (host-checked)
     else if (yt) UR_EPI_PASS(0, 2, 0, 1, 2);                                                    // fused QKV with transposed V
@@ -348,28 +323,37 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
   if (p.dbg & 16) return;
   __syncthreads();
   if (p.gn_fused) {
-    // Fused GroupNorm statistics of the tile just produced (exactly the bf16 values the consumer will read):
-    // thread (g, cp) sums column pair cp over row group g from LDS, row groups meet in LDS, then ONE fp64 atomic
-    // per (column, moment) per workgroup.  The host only sets gn_fused when a tile never straddles two images.
+    // Fused GroupNorm statistics of the tile just produced (exactly the 16-bit values the consumer will read), deterministic:
+    // thread (g, cp) sums column pair cp over row group g from LDS into red[g][moment][cp]; one thread per column then adds
+    // the row groups in order and stores the tile's partial (sum, sum of squares) - a plain store into this tile's own slot
+    // of the partial plane [N][P][C][2] (no atomics; the host only sets gn_fused when a tile never straddles two images).
+    float* red = sbias;                                   // bias / LayerNorm staging is dead by now: [NG][4][CP] floats (<= 4*NT)
     const int CP = ncols >> 1, NG = NT / CP, RGN = (BM + NG - 1) / NG;
     const int cp = threadIdx.x % CP, g = threadIdx.x / CP;
-    if (g < NG && cp * 2 < cmax) {
-      const int r0 = g * RGN, r1 = p.patch_tw ? min(BM, r0 + RGN) : min(min(BM, r0 + RGN), p.M - m0);
+    if (g < NG) {
       float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-      for (int r = r0; r < r1; ++r) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * SROW + cp * 4);
-        const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
-        s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+      if (cp * 2 < cmax) {
+        const int r0 = g * RGN, r1 = p.patch_tw ? min(BM, r0 + RGN) : min(min(BM, r0 + RGN), p.M - m0);
+        for (int r = r0; r < r1; ++r) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * SROW + cp * 4);
+          const float a = Act<F16>::lo(w), b = Act<F16>::hi(w);
+          s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+        }
       }
-      atomicAdd(&facc[cp * 2], s0); atomicAdd(&facc[cp * 2 + 1], s1);
-      atomicAdd(&facc[BN + cp * 2], q0); atomicAdd(&facc[BN + cp * 2 + 1], q1);
+      red[(g * 4 + 0) * CP + cp] = s0; red[(g * 4 + 1) * CP + cp] = s1;
+      red[(g * 4 + 2) * CP + cp] = q0; red[(g * 4 + 3) * CP + cp] = q1;
     }
     __syncthreads();
     const int ctot = pair ? p.Cout / 2 : p.Cout;
-    double* st = p.gn_stats + ((long long)(m0 / p.OHW) * p.nbatch * ctot + (long long)gb * ctot + c0) * 2;
+    const int img = m0 / p.OHW, rem = m0 - img * p.OHW;
+    // partial slot of this tile inside its image: linear tiles = row block; halo patches = (patch row, patch column)
+    const int pm = p.patch_tw ? ((rem / p.OW) / (BM / p.patch_tw)) * (p.OW / p.patch_tw) + (rem % p.OW) / p.patch_tw : rem / BM;
+    float* st = p.gn_part + ((((long long)img * p.gn_parts + pm) * p.nbatch + gb) * ctot + c0) * 2;
     for (int i = threadIdx.x; i < cmax; i += NT) {
-      atomicAdd(&st[2 * i], (double)facc[i]);
-      atomicAdd(&st[2 * i + 1], (double)facc[BN + i]);
+      const int c2 = i >> 1, odd = i & 1;
+      float a = 0.f, b = 0.f;
+      for (int gg = 0; gg < NG; ++gg) { a += red[(gg * 4 + odd) * CP + c2]; b += red[(gg * 4 + 2 + odd) * CP + c2]; }
+      *reinterpret_cast<float2*>(st + 2 * i) = make_float2(a, b);
     }
   }
   if (p.row_stats) {
@@ -383,7 +367,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
       float sx = 0.f, sq = 0.f;
       for (int j = part * per; j < min(npair, (part + 1) * per); ++j) {
         const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * SROW + j * 4);
-        const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
+        const float a = Act<F16>::lo(w), b = Act<F16>::hi(w);
         sx += a + b; sq += a * a + b * b;
       }
       if (TPR >= 2) { sx += __shfl_xor(sx, 1, 64); sq += __shfl_xor(sq, 1, 64); }
@@ -394,14 +378,23 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
         *reinterpret_cast<float2*>(p.row_stats + 2 * ((long long)tn_idx * p.M + m)) = make_float2(sx, sq);
     }
   }
+  if (!p.y) return;                                      // statistics-only launch (pooled output): nothing to store
   uint16_t* yb = reinterpret_cast<uint16_t*>(p.y) + gb * p.bs_y;
   if (pair) tile_copy<BM, (BN >= 16 ? BN / 2 : 8), NT, SROW, false>(p, yb, p.ldy, smem, m0, p.M, c0, cmax);
   else tile_copy<BM, BN, NT, SROW, false>(p, yb, p.ldy, smem, m0, p.M, c0, cmax);
 }
 
+// LDS bytes the staged epilogue needs (tile + bias / LayerNorm staging, reused for the GroupNorm partial reduction)
+template <int BM, int BN, int NT, bool PAIRC = false>
+constexpr int epi_lds_bytes() {
+  constexpr int tile = BM * ((PAIRC ? BN : BN * 2) + 8);
+  constexpr int aux1 = 5 * BN * 4 + BM * 8, aux2 = 4 * NT * 4;
+  return tile + (aux1 > aux2 ? aux1 : aux2);
+}
+
 // DIRECT_OK = false: the kernel is only ever launched with a staged-capable output (host-checked), so the unstaged
 // store path is not compiled in (its FN x FM x 4 unrolled stores are pure code-size ballast there).
-template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, bool DIRECT_OK = true, bool PAIRC = false>
+template <int FM, int FN, int WTM, int WTN, int BM, int BN, int NT, bool F16, bool DIRECT_OK = true, bool PAIRC = false>
 __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
                                                int gb, int sz, unsigned char* smem, bool owner = true) {
   // owner: this wave holds accumulator fragments (false for the loader waves of the warp-specialised kernel,
@@ -432,16 +425,16 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   const bool bias_geom_ok = !p.bias_img || p.patch_tw || (p.OHW % BM) == 0 || ((BM % p.OHW) == 0 && nimg_tile <= 4);
   const bool staged = p.staged_ok_ && BN >= 32 && bias_geom_ok;   // host-evaluated part: bf16 y, 16-byte aligned rows, no colsum
   if (!staged) {
-    if (DIRECT_OK && owner) igemm_epilogue_direct<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, gb);
+    if (DIRECT_OK && owner) igemm_epilogue_direct<FM, FN, WTM, WTN, F16>(p, acc, m0, n0, wm, wn, lane, gb);
     return;
   }
   const bool plain = !pair && !p.ln_stats && nimg_tile == 1 && !p.yt;
-  if (PAIRC) { if (!plain) staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 1, true>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile); }
-  else if (plain) staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 0>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
-  else staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 1>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
+  if (PAIRC) { if (!plain) staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 1, true, F16>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile); }
+  else if (plain) staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 0, false, F16>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
+  else staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 1, false, F16>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
 }
 
-template <int BM, int BN, int WM, int WN, bool G1 = false>
+template <int BM, int BN, int WM, int WN, bool G1, bool F16>
 __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
   // G1: pure GEMM (1x1, stride 1, one source, no padding): rows are plain offsets, no im2col state, no tap bookkeeping
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, XP = BM / 32, WP = BN / 32;
@@ -577,22 +570,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int slot = ks * 2 + fhalf;
-      bf16x8 bfr[FM], afr[FN];
+      uint4 bfr[FM], afr[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
         int row = wm * WTM + b * 32 + frow;
-        bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        bfr[b] = *reinterpret_cast<const uint4*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
         int row = wn * WTN + a * 32 + frow;
-        afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
     }
   };
 
@@ -612,9 +605,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     }
   }
 
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, 256>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, 256, F16>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p) {
   const bool pair = is_pair_act(p.act);
   const int qn = p.Cout / 4;  // quads per row in GEMM N space
@@ -636,18 +630,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvK p) {
       }
     }
     int co = epi_act(p, gb, m, co_in, v, g);
-    if (p.colsum) {
-      int cw = pair ? p.Cout / 2 : p.Cout;
-      for (int e = 0; e < 4; ++e)
-        atomicAdd(p.colsum + ((long long)(m / p.OHW) * p.nbatch + gb) * cw + co + e, v[e] * p.colsum_scale);
-    }
-    epi_store(p, gb, m, co, v);
+    epi_store<F16>(p, gb, m, co, v);
   }
 }
 
 // Split-K reduce for GEMMs that take part in LayerNorm folding: one wave per output row, so the row owns its
 // LayerNorm statistics - the consumer transform rstd*(acc - mean*s[n]) is applied to the reduced sums, and the
 // producer's (sum, sumsq) of the bf16 values written goes out as ONE plane (ln_parts == 1 for the next GEMM).
+template <bool F16>
 __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const ConvK p) {
   const bool pair = is_pair_act(p.act);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -690,13 +680,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const ConvK p) 
       const int co = epi_act(p, 0, m, co_in, v, g);
       if (p.res) {
         const uint2 rv = *reinterpret_cast<const uint2*>(p.res + (long long)m * p.ldr + co);
-        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+        v[0] += Act<F16>::lo(rv.x); v[1] += Act<F16>::hi(rv.x);
+        v[2] += Act<F16>::lo(rv.y); v[3] += Act<F16>::hi(rv.y);
       }
-      const uint2 o = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      const uint2 o = make_uint2(Act<F16>::pack2(v[0], v[1]), Act<F16>::pack2(v[2], v[3]));
       *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.ldy + co) = o;
-      const float a0 = __uint_as_float(o.x << 16), a1 = __uint_as_float(o.x & 0xffff0000u);
-      const float a2 = __uint_as_float(o.y << 16), a3 = __uint_as_float(o.y & 0xffff0000u);
+      const float a0 = Act<F16>::lo(o.x), a1 = Act<F16>::hi(o.x);
+      const float a2 = Act<F16>::lo(o.y), a3 = Act<F16>::hi(o.y);
       rsx += (a0 + a1) + (a2 + a3);
       rsq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     }
@@ -713,7 +703,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const ConvK p) 
 // there is split-K, and each used to be followed by a separate statistics pass).  Block = 16 column quads x 16 row
 // lanes over 64 consecutive rows of ONE image (host guarantees OHW % 64 == 0); column sums stay in registers, the
 // row lanes meet in LDS, then one fp64 atomic per (column, moment) per block.
-template <int RI>   // rows per block = 16 * RI (one image: host checks OHW % (16 * RI) == 0)
+template <int RI, bool F16>   // rows per block = 16 * RI (one image: host checks OHW % (16 * RI) == 0)
 __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
   __shared__ float red[16][16][9];
   const int qc = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -739,12 +729,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
     for (int i = 0; i < RI; ++i) {
       const int m = r0 + rl + 16 * i;
       epi_act(p, 0, m, co, v[i], g);
-      v[i][0] += __uint_as_float(rv[i].x << 16); v[i][1] += __uint_as_float(rv[i].x & 0xffff0000u);
-      v[i][2] += __uint_as_float(rv[i].y << 16); v[i][3] += __uint_as_float(rv[i].y & 0xffff0000u);
-      const uint2 o = make_uint2(pack2bf(v[i][0], v[i][1]), pack2bf(v[i][2], v[i][3]));
+      v[i][0] += Act<F16>::lo(rv[i].x); v[i][1] += Act<F16>::hi(rv[i].x);
+      v[i][2] += Act<F16>::lo(rv[i].y); v[i][3] += Act<F16>::hi(rv[i].y);
+      const uint2 o = make_uint2(Act<F16>::pack2(v[i][0], v[i][1]), Act<F16>::pack2(v[i][2], v[i][3]));
       *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.ldy + co) = o;
-      const float a[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
-                          __uint_as_float(o.y & 0xffff0000u)};
+      const float a[4] = {Act<F16>::lo(o.x), Act<F16>::hi(o.x), Act<F16>::lo(o.y), Act<F16>::hi(o.y)};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { sm[e] += a[e]; sq[e] += a[e] * a[e]; }
     }
@@ -752,7 +741,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) { red[rl][qc][e] = sm[e]; red[rl][qc][4 + e] = sq[e]; }
   __syncthreads();
-  // 128 (column quad, moment-lane) sums of 16 row lanes each, then one fp64 atomic per (column, moment)
+  // 128 (column quad, moment-lane) sums of 16 row lanes each, in row-lane order, stored into this block's own slot of the
+  // partial plane [N][P][Cout][2] (P = OHW / (16 * RI); no atomics)
   if (threadIdx.x < 128) {
     const int c = threadIdx.x >> 3, e = threadIdx.x & 7;
     const int qq = blockIdx.x * 16 + c;
@@ -760,29 +750,76 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
       float a = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) a += red[r][c][e];
-      double* st = p.gn_stats + ((long long)(r0 / p.OHW) * p.Cout + qq * 4) * 2;
-      atomicAdd(&st[2 * (e & 3) + (e >> 2)], (double)a);
+      const int img = r0 / p.OHW, pm = (r0 - img * p.OHW) / (16 * RI);
+      float* st = p.gn_part + (((long long)img * p.gn_parts + pm) * p.Cout + qq * 4) * 2;
+      st[2 * (e & 3) + (e >> 2)] = a;
     }
   }
 }
 
-// picks the reduce pass of a split-K launch (and records whether it produced the GroupNorm statistics)
-static void launch_splitk_reduce(ConvK& k, hipStream_t s) {
+// Each instantiation unit is compiled twice (-DUR_TU_F16=0 / 1): one object per 16-bit type, so that the two sets of kernels
+// build in parallel.  URK(name) is the unit's exported launcher for its type; igemm.hip picks by ConvK::f16.
+#ifndef UR_TU_F16
+#define UR_TU_F16 0
+#endif
+#if UR_TU_F16
+#define URK(name) name##_f16
+#else
+#define URK(name) name##_bf16
+#endif
+#define UR_F16_SWITCH(k, ...)                  \
+  do {                                         \
+    constexpr bool F16 = UR_TU_F16 != 0;       \
+    __VA_ARGS__;                               \
+  } while (0)
+
+// reduce pass of a split-K launch: 0 = plain, 1 = row-wise (LayerNorm fusion), 2 = GroupNorm partials (16 * ri rows per block)
+struct ReducePlan { int kind, ri; };
+static ReducePlan plan_splitk_reduce(const ConvK& k) {
   const bool pair = k.act == UR_ACT_GEGLU || k.act == UR_ACT_GATE;
-  if (k.row_stats || k.ln_stats) {
-    hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(std::min((k.M + 3) / 4, 4096)), dim3(256), 0, s, k);
-  } else if (!getenv("UR_IGEMM_NOGNRED") && k.gn_stats && !pair && k.staged_ok_ && k.nbatch == 1 && !k.yt && k.OHW % 64 == 0 && !k.patch_tw) {
+  if (k.row_stats || k.ln_stats) return {1, 0};
+  static const bool no_gnred = getenv("UR_IGEMM_NOGNRED") != nullptr;
+  if (!no_gnred && k.gn_part && k.y && !pair && k.staged_ok_ && k.nbatch == 1 && !k.yt && k.OHW % 64 == 0) {
     // rows per block 64 / 32 / 16: the largest that still gives >= 512 workgroups (M = 512 at the 8x8 level needs the
     // 16-row version: 160 workgroups of 64 rows left a third of the CUs idle in a latency-bound pass)
     const long long colb = (k.Cout / 4 + 15) / 16;
-    if (colb * (k.M / 64) >= 512) hipLaunchKernelGGL(splitk_reduce_gn_kernel<4>, dim3(colb, k.M / 64), dim3(256), 0, s, k);
-    else if (colb * (k.M / 32) >= 512) hipLaunchKernelGGL(splitk_reduce_gn_kernel<2>, dim3(colb, k.M / 32), dim3(256), 0, s, k);
-    else hipLaunchKernelGGL(splitk_reduce_gn_kernel<1>, dim3(colb, k.M / 16), dim3(256), 0, s, k);
-    k.gn_fused = 1;
+    if (colb * (k.M / 64) >= 512) return {2, 4};
+    if (colb * (k.M / 32) >= 512) return {2, 2};
+    return {2, 1};
+  }
+  return {0, 0};
+}
+
+// Where the GroupNorm partial plane of this launch comes from (decided BEFORE the launch so that the dry-run plan and the
+// real launch agree): the conv epilogue (one partial per M tile of an image), the split-K reduce, or an extra pass over y.
+static void set_gn_plan(ConvK& k, bool direct_ok, int direct_parts) {
+  k.gn_fused = 0; k.gn_parts = 0;
+  if (!k.gn_part) return;
+  if (k.splitk == 1) {
+    if (direct_ok) { k.gn_fused = 1; k.gn_parts = direct_parts; }
+  } else {
+    const ReducePlan r = plan_splitk_reduce(k);
+    if (r.kind == 2) { k.gn_fused = 1; k.gn_parts = k.OHW / (16 * r.ri); }
+  }
+  if (!k.gn_fused) {
+    const bool pair = k.act == UR_ACT_GEGLU || k.act == UR_ACT_GATE;
+    k.gn_parts = ur::gn_stats_parts(k.N, k.OHW, (pair ? k.Cout / 2 : k.Cout) * k.nbatch);
+  }
+}
+
+static void launch_splitk_reduce(ConvK& k, hipStream_t s) {
+  const ReducePlan r = plan_splitk_reduce(k);
+  if (r.kind == 1) {
+    UR_F16_SWITCH(k, hipLaunchKernelGGL(splitk_reduce_rows_kernel<F16>, dim3(std::min((k.M + 3) / 4, 4096)), dim3(256), 0, s, k));
+  } else if (r.kind == 2) {
+    const long long colb = (k.Cout / 4 + 15) / 16;
+    if (r.ri == 4) UR_F16_SWITCH(k, hipLaunchKernelGGL((splitk_reduce_gn_kernel<4, F16>), dim3(colb, k.M / 64), dim3(256), 0, s, k));
+    else if (r.ri == 2) UR_F16_SWITCH(k, hipLaunchKernelGGL((splitk_reduce_gn_kernel<2, F16>), dim3(colb, k.M / 32), dim3(256), 0, s, k));
+    else UR_F16_SWITCH(k, hipLaunchKernelGGL((splitk_reduce_gn_kernel<1, F16>), dim3(colb, k.M / 16), dim3(256), 0, s, k));
   } else {
     long long total = (long long)k.nbatch * k.M * (k.Cout / 4);
     int rb = (int)std::min<long long>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, k);
+    UR_F16_SWITCH(k, hipLaunchKernelGGL(splitk_reduce_kernel<F16>, dim3(rb), dim3(256), 0, s, k));
   }
 }
 
@@ -792,7 +829,7 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   k.tiles_n = (k.Cout + BN - 1) / BN;
   const long long blocks = (long long)k.tiles_m * k.tiles_n * k.nbatch;
   int splitk = 1;
-  if (blocks < 200 && k.nk >= 8 && k.ws) {
+  if (blocks < 200 && k.nk >= 8 && k.ws && k.y) {      // (a statistics-only launch has no y for a reduce pass to write)
     long long want = (384 + blocks - 1) / blocks;
     long long cap_k = k.nk / 4;
     splitk = (int)std::min<long long>(std::min<long long>(want, cap_k), 16);
@@ -803,23 +840,22 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   k.splitk = splitk;
   k.nk_per_split = (k.nk + splitk - 1) / splitk;
   k.splitk = (k.nk + k.nk_per_split - 1) / k.nk_per_split;
+  set_gn_plan(k, k.staged_ok_ && BN >= 32 && (k.OHW % BM) == 0, k.OHW / BM);
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }     // row-stat planes this launch writes
-  k.gn_fused = k.gn_stats && k.staged_ok_ && k.splitk == 1 && BN >= 32 && (k.OHW % BM) == 0;
   constexpr int lds = 2 * (BM + BN) * 128;
+  static_assert(epi_lds_bytes<BM, BN, 256>() <= lds, "epilogue staging must fit the K ring");
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, false, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, true, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
   static const bool no_g1 = getenv("UR_IGEMM_NOG1") != nullptr;
   const bool g1 = !no_g1 && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.pad_t == 0 && k.pad_l == 0 && k.OH == k.H && k.OW == k.W &&
                   (long long)k.M * k.ldx + k.Ktot < (1ll << 31);
-  if (g1) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), lds, s, k);
-  else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), lds, s, k);
+  if (g1) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, F16>), grid, dim3(256), lds, s, k));
+  else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, F16>), grid, dim3(256), lds, s, k));
   if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
 }
@@ -833,7 +869,7 @@ int launch_cfg(ConvK& k, hipStream_t s) {
 //   * padded / out-of-range pieces read a 16-byte zero page instead of being predicated (every wave issues the
 //     same number of DMA ops per tile, so one immediate vmcnt(N) is right for all waves);
 //   * no VGPR staging: the ring is NST-1 tiles ahead of the MFMAs (HBM/L2 latency hidden across barriers).
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, bool F16>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) {
   constexpr int NT = WM * WN * 64, RPP = NT / 8;                  // threads; tile rows covered by one loader pass
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
@@ -943,22 +979,22 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int slot = ks * 2 + fhalf;
-      bf16x8 bfr[FM], afr[FN];
+      uint4 bfr[FM], afr[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
         int row = wm * WTM + b * 32 + frow;
-        bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        bfr[b] = *reinterpret_cast<const uint4*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
         int row = wn * WTN + a * 32 + frow;
-        afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
     }
   };
 
@@ -986,14 +1022,14 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
     }
   }
   if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.y)[0] = 1.f; return; }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
 }
 
 // Pure-GEMM specialisation of the LDS-DMA ring (1x1 / Linear, single source): row base offsets are 32-bit element
 // offsets and nothing else is kept per row, which leaves room for 256 x 256 tiles (128 accumulator registers per wave).
 // Large-N GEMMs (GEGLU, fused QKV) are L2->CU ingest bound: at 128 x 128 tiles every flop costs 1/64 B of ingest,
 // at 256 x 256 half of that.
-template <int BM, int BN, int WM, int WN, int NST, bool DIRECT = false, bool PAIRC = false>
+template <int BM, int BN, int WM, int WN, int NST, bool DIRECT, bool PAIRC, bool F16>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
   constexpr int NT = WM * WN * 64, RPP = NT / 8;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
@@ -1064,49 +1100,48 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int slot = ks * 2 + fhalf;
-      bf16x8 bfr[FM], afr[FN];
+      uint4 bfr[FM], afr[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
         const int row = wm * WTM + b * 32 + frow;
-        bfr[b] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        bfr[b] = *reinterpret_cast<const uint4*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
         const int row = wn * WTN + a * 32 + frow;
-        afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
     }
     cs = (cs + 1 == NST) ? 0 : cs + 1;
     if (NST >= 3 && issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, DIRECT, PAIRC>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, DIRECT, PAIRC>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
 }
 
 template <int BM, int BN, int WM, int WN, int NST, bool DIRECT = false, bool PAIRC = false>
 int launch_gemm(ConvK& k, hipStream_t s) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.Cout + BN - 1) / BN;
-  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
   k.splitk = 1;
   k.nk_per_split = k.nk;
-  k.gn_fused = k.gn_stats && k.staged_ok_ && (k.OHW % BM) == 0;
-  constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = BM * ((PAIRC ? BN : BN * 2) + 8) + 7 * BN * 4 + BM * 8;
+  set_gn_plan(k, k.staged_ok_ && (k.OHW % BM) == 0, k.OHW / BM);
+  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
+  constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = epi_lds_bytes<BM, BN, WM * WN * 64, PAIRC>();
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k);
+  UR_F16_SWITCH(k, hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC, F16>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k));
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
@@ -1114,10 +1149,9 @@ template <int BM, int BN, int WM, int WN, int NST>
 int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
   k.tiles_m = (k.M + BM - 1) / BM;
   k.tiles_n = (k.Cout + BN - 1) / BN;
-  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
   const long long blocks = (long long)k.tiles_m * k.tiles_n * k.nbatch;
   int splitk = 1;
-  if (blocks < min_blocks && k.nk >= 8 && k.ws && !k.row_stats && !k.ln_stats) {
+  if (blocks < min_blocks && k.nk >= 8 && k.ws && k.y && !k.row_stats && !k.ln_stats) {
     long long want = (256 + blocks - 1) / blocks;
     splitk = (int)std::min<long long>(std::min<long long>(want, k.nk / 4), 16);
     while (splitk > 1 && (long long)splitk * k.nbatch * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
@@ -1125,20 +1159,40 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
   }
   k.nk_per_split = (k.nk + splitk - 1) / splitk;
   k.splitk = (k.nk + k.nk_per_split - 1) / k.nk_per_split;
-  k.gn_fused = k.gn_stats && k.staged_ok_ && k.splitk == 1 && BN >= 32 && (k.OHW % BM) == 0;
-  constexpr int lds = NST * (BM + BN) * 128;
+  set_gn_plan(k, k.staged_ok_ && BN >= 32 && (k.OHW % BM) == 0, k.OHW / BM);
+  if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
+  constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = epi_lds_bytes<BM, BN, WM * WN * 64>();
+  constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, WM, WN, NST>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, WM, WN, NST, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
-  hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, WM, WN, NST>), grid, dim3(WM * WN * 64), lds, s, k);
+  UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, WM, WN, NST, F16>), grid, dim3(WM * WN * 64), lds, s, k));
   if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
 }
 
+
+// GroupNorm apply (+ SiLU) on one 16-byte piece of an LDS-resident input patch, in place: 8 channels of one pixel,
+// v <- act(a[c] * v + b[c]) with (a, b) taken from the LDS copy of this chunk's affine table (fp32 a[64] | b[64], the table
+// ur_groupnorm_finalize produced).  Zero-padding pieces are never touched (the convolution pads the NORMALISED tensor).
+template <bool F16>
+__device__ __forceinline__ void gn_piece_inplace(unsigned char* piece, const unsigned char* abuf, int chunk, bool silu) {
+  const float4 a0 = *reinterpret_cast<const float4*>(abuf + chunk * 32), a1 = *reinterpret_cast<const float4*>(abuf + chunk * 32 + 16);
+  const float4 b0 = *reinterpret_cast<const float4*>(abuf + 256 + chunk * 32), b1 = *reinterpret_cast<const float4*>(abuf + 256 + chunk * 32 + 16);
+  const uint4 v = *reinterpret_cast<const uint4*>(piece);
+  float f[8];
+  unpack8t<F16>(v, f);
+  f[0] = fmaf(f[0], a0.x, b0.x); f[1] = fmaf(f[1], a0.y, b0.y); f[2] = fmaf(f[2], a0.z, b0.z); f[3] = fmaf(f[3], a0.w, b0.w);
+  f[4] = fmaf(f[4], a1.x, b1.x); f[5] = fmaf(f[5], a1.y, b1.y); f[6] = fmaf(f[6], a1.z, b1.z); f[7] = fmaf(f[7], a1.w, b1.w);
+  if (silu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+  }
+  *reinterpret_cast<uint4*>(piece) = pack8t<F16>(f);
+}
 
 // =====================================================================================================================
 // Halo-tile 3x3 convolution (stride 1, pad 1, optional nearest-2x upsampled input).
@@ -1150,7 +1204,7 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
 // K tile (3-stage ring).  Ingest per K tile drops from (256+BN)*128 B to ~BN*128 B + 5 KB.
 // A fragment is one 32-pixel patch row, so its LDS rows are consecutive for every tap and the (row>>1)&7 slot swizzle
 // stays conflict-free (tools/lds_conflicts.py model; a 16x16 patch would be 2-way conflicted on every tap).
-template <int TH, int BN, int WM, int WN>
+template <int TH, int BN, int WM, int WN, bool F16>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) {
   constexpr int NW = WM * WN, TW = 32, BM = TH * TW, PW = TW + 2, HPIX = (TH + 2) * PW;   // 340 (TH=8) / 204 (TH=4) halo pixels
   constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);                              // tap slots that carry a halo piece
@@ -1161,6 +1215,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const hbuf = smem;                      // 2 halo patches
   unsigned char* const wring = smem + 2 * HBYTES;        // 3 weight tiles
+  unsigned char* const abuf = wring + 3 * WBYTES;        // 2 x 1 KiB: GroupNorm affine (a[64] | b[64]) of the current / next chunk
+  // GroupNorm apply (+ SiLU) of the input fused into the loader (ur_conv_desc.gn_ab): every wave rewrites the halo pieces IT
+  // fetched, in LDS, two taps after issuing them (its own vmcnt covers them) - the normalised tensor never exists in HBM.
+  const bool gnp = p.gn_ab != nullptr;
+  static_assert(HSLOTS <= 7, "the in-LDS GroupNorm pass needs taps 2 .. HSLOTS+1 <= 8");
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid % WM, wn = wid / WM;
@@ -1227,6 +1286,18 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     const uint16_t* g = hpix[t] >= 0 ? src + hpix[t] * ld + cc : zero;
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(hbuf + (c & 1) * HBYTES + q * 1024), 16, 0, 0);
   };
+  // affine table of chunk c -> abuf[c & 1]: lanes 0-15 fetch a[64], lanes 16-31 b[64] (fp32), the rest a zero page.  Every
+  // wave issues the same piece to the same place (identical bytes), so each may read it back after its OWN vmcnt and the
+  // per-iteration DMA count stays wave-uniform.
+  auto issue_ab = [&](int c) {
+    const float* t = p.gn_ab + ((long long)img * 2 + (lane >> 4 & 1)) * p.Cin + (c_begin + c) * 64 + (lane & 15) * 4;
+    const void* g = lane < 32 ? (const void*)t : (const void*)zero;
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (c & 1) * 1024), 16, 0, 0);
+  };
+  auto gn_slot = [&](int c, int t) {                      // this wave's halo piece t of chunk c, in place
+    if (hpix[t] >= 0)
+      gn_piece_inplace<F16>(hbuf + (c & 1) * HBYTES + (t * NW + wid) * 1024 + lane * 16, abuf + (c & 1) * 1024, chunk, p.gn_silu != 0);
+  };
 
   f32x16 acc[FN][FM];
 #pragma unroll
@@ -1238,6 +1309,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
   const int frow = lane & 31, fhalf = lane >> 5;
 
   // ---- prologue: whole halo of chunk 0, weight tiles 0 and 1 ------------------------------------------------------------
+  if (gnp) issue_ab(0);
 #pragma unroll
   for (int t = 0; t < HSLOTS; ++t) issue_h(0, t);
   issue_w(0, 0);
@@ -1246,6 +1318,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (gnp) {                                              // chunk 0's patch is normalised before anyone reads it
+#pragma unroll
+    for (int t = 0; t < HSLOTS; ++t) gn_slot(0, t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
 
@@ -1262,70 +1339,79 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
       const bool more_h = tap < HSLOTS && next_chunk;
       if (more_w) issue_w(kt + 2, (tap + 2) % 3);
       if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
+      const bool ab_now = gnp && tap == 0 && next_chunk;    // (+1 DMA op in this iteration, counted in the wait below)
+      if (ab_now) issue_ab(c + 1);
+      // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it under this tap's MFMAs
+      if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, tap >= 2 ? tap - 2 : 0);
       {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const int slot = ks * 2 + fhalf;
-          bf16x8 bfr[FM], afr[FN];
+          uint4 bfr[FM], afr[FN];
 #pragma unroll
           for (int b = 0; b < FM; ++b) {
             const int hrow = (wm * FM + b + dy) * PW + dx + frow;
-            bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
+            bfr[b] = *reinterpret_cast<const uint4*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
           }
 #pragma unroll
           for (int a = 0; a < FN; ++a) {
             const int row = wn * WTN + a * 32 + frow;
-            afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+            afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
           }
 #pragma unroll
           for (int a = 0; a < FN; ++a)
 #pragma unroll
             for (int b = 0; b < FM; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
         }
       }
       // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
-      if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
+      if (ab_now) {                                       // tap 0 with the next chunk's affine table in flight as well
+        if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
       else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
       else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (gnp) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the in-place GroupNorm writes are published by the barrier
       __builtin_amdgcn_s_barrier();
     }
   }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 }
 
 template <int TH, int BN, int WM, int WN>
 int launch_halo(ConvK& k, hipStream_t s) {
   constexpr int NW = WM * WN, BM = TH * 32, HPIX = (TH + 2) * 34, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
   constexpr int HBYTES = HSLOTS * NW * 1024;
-  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = BM * (BN * 2 + 8) + 7 * BN * 4 + BM * 8;
+  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128 + 2048, lds_epi = epi_lds_bytes<BM, BN, NW * 64>();     // (+ 2 x 1 KiB affine tables)
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  k.prologue_ok = 1;
   k.tiles_m = k.N * (k.OH / TH) * (k.OW / 32);
   k.tiles_n = (k.Cout + BN - 1) / BN;
   const int nchunk = k.nk / 9;
   const long long tiles = (long long)k.tiles_m * k.tiles_n;
   int splitk = 1;
   static const bool no_hsplit = getenv("UR_IGEMM_NOHSPLIT") != nullptr;
-  if (!no_hsplit && tiles <= 128 && k.ws && !k.colsum) {     // <= half a round of CUs: split the chunk range, reduce in a second pass
+  if (!no_hsplit && tiles <= 128 && k.ws && k.y) {     // <= half a round of CUs: split the chunk range, reduce in a second pass
     splitk = (int)std::min<long long>(256 / tiles, std::max(1, nchunk / 2));
     while (splitk > 1 && (long long)splitk * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
   }
   const int cps = (nchunk + splitk - 1) / splitk;
   k.splitk = (nchunk + cps - 1) / cps;
   k.nk_per_split = cps * 9;
+  set_gn_plan(k, true, (k.OH / TH) * (k.OW / 32));         // a patch never leaves its image: one partial per patch
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
   k.patch_tw = 32;
-  k.gn_fused = k.gn_stats != nullptr && k.splitk == 1;     // a patch never leaves its image
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k);
+  UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
   if (k.splitk > 1) {
     k.patch_tw = 0;                                        // the partial planes are plain [M][Cout]
     launch_splitk_reduce(k, s);
@@ -1341,7 +1427,7 @@ int launch_halo(ConvK& k, hipStream_t s) {
 // because these layers have few tiles and K = 9 x 1280..2560.  A 32-pixel fragment spans several image rows; the slot
 // swizzle f(row) = ((row_in_image >> 1) - halo_y) & 7 keeps its ds_read_b128 conflict-free for both shapes
 // (searched with tools/lds_conflicts.py), at the price of a per-piece source chunk on the DMA side.
-template <int TH, int TW, int NIMG, int BN, int WM, int WN>
+template <int TH, int TW, int NIMG, int BN, int WM, int WN, bool F16>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK p) {
   constexpr int NW = WM * WN, BM = TH * TW * NIMG, PW = TW + 2, HP = (TH + 2) * PW, HPIX = HP * NIMG;
   constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
@@ -1466,36 +1552,40 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const int slot = ks * 2 + fhalf;
-          bf16x8 bfr[FM], afr[FN];
+          uint4 bfr[FM], afr[FN];
 #pragma unroll
-          for (int b = 0; b < FM; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(hb + hro[b] + ((slot ^ hsw[b]) << 4));
+          for (int b = 0; b < FM; ++b) bfr[b] = *reinterpret_cast<const uint4*>(hb + hro[b] + ((slot ^ hsw[b]) << 4));
 #pragma unroll
           for (int a = 0; a < FN; ++a) {
             const int row = wn * WTN + a * 32 + frow;
-            afr[a] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+            afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
           }
 #pragma unroll
           for (int a = 0; a < FN; ++a)
 #pragma unroll
             for (int b = 0; b < FM; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
         }
       }
-      if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
+      if (ab_now) {                                       // tap 0 with the next chunk's affine table in flight as well
+        if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
       else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
       else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (gnp) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the in-place GroupNorm writes are published by the barrier
       __builtin_amdgcn_s_barrier();
     }
   }
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 }
 
 template <int TH, int TW, int NIMG, int BN, int WM, int WN>
 int launch_halo_img(ConvK& k, hipStream_t s) {
   constexpr int NW = WM * WN, BM = TH * TW * NIMG, HPIX = (TH + 2) * (TW + 2) * NIMG, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
   constexpr int HBYTES = HSLOTS * NW * 1024;
-  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = BM * (BN * 2 + 8) + 7 * BN * 4 + BM * 8;
+  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = epi_lds_bytes<BM, BN, NW * 64>();
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   k.tiles_m = (k.N + NIMG - 1) / NIMG;
@@ -1503,22 +1593,21 @@ int launch_halo_img(ConvK& k, hipStream_t s) {
   const int nchunk = k.nk / 9;
   const long long tiles = (long long)k.tiles_m * k.tiles_n;
   int splitk = 1;
-  if (tiles < 200 && k.ws) {      // one workgroup per CU: split the chunk range so that tiles * splits <= 256 (a single round)
+  if (tiles < 200 && k.ws && k.y) {      // one workgroup per CU: split the chunk range so that tiles * splits <= 256 (a single round)
     splitk = (int)std::min<long long>(std::max<long long>(256 / tiles, 1), std::max(1, nchunk / 2));
     while (splitk > 1 && (long long)splitk * k.M * k.Cout * 4 > (long long)k.ws_bytes_) --splitk;
   }
   const int cps = (nchunk + splitk - 1) / splitk;
   k.splitk = (nchunk + cps - 1) / cps;
   k.nk_per_split = cps * 9;
+  set_gn_plan(k, (k.OHW % BM) == 0, k.OHW / BM);
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
-  k.gn_fused = k.gn_stats && k.splitk == 1 && (k.OHW % BM) == 0;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k);
+  UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
   if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
 }

@@ -8,22 +8,25 @@
 
 namespace {
 
-// ---- GroupNorm pass 1: per-(image, channel) sum / sum-of-squares -----------------------------------------------
-// grid = (pixel chunks, N, channel slabs).  A slab is CVS <= 32 channel vectors (8 channels each); thread (r, v)
-// owns vector v of the slab and pixel rows r, r+R, ... (R = 256/CVS), so a warp reads whole contiguous row pieces.
-// Block partials are combined with LDS atomics and leave as ONE fp64 atomic per channel per block.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ x, double* __restrict__ stats,
-                                                       int HW, int C, int pix_per_block, int c_off, int C_total, int CVS) {
-  __shared__ float lds[2 * 256];
-  const int n = blockIdx.y, t = threadIdx.x;
+// ---- GroupNorm / InstanceNorm / average-pool statistics: DETERMINISTIC partial planes ---------------------------------
+// part[N][P][C][2] fp32: partial (sum, sum of squares) of image n, pixel chunk p, channel c.  Every entry is written by
+// exactly one workgroup with plain stores (no atomics anywhere), the finalize kernel adds the P partials of a group in a
+// fixed order in fp64 - two replays of the same graph are bit-identical.  Conv / GEMM epilogues write the same layout
+// (ur_conv_desc.gn_part), so a GroupNorm whose producer left partials needs no statistics pass at all.
+//
+// pass 1 (only for tensors without producer-side partials): grid = (pixel chunks, N, channel slabs).  A slab is
+// CVS <= 32 channel vectors (8 channels each); thread (r, v) owns vector v of the slab and pixel rows r, r+R, ...
+template <bool F16>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ part,
+                                                       int HW, int C, int pix_per_block, int CVS) {
+  __shared__ float lds[256 * 16];
+  const int n = blockIdx.y, t = threadIdx.x, P = gridDim.x;
   const int CV = C >> 3, R = 256 / CVS;
   const int r = t / CVS, vl = t - r * CVS, v = blockIdx.z * CVS + vl;
   const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
-  for (int i = t; i < 2 * CVS * 8; i += 256) lds[i] = 0.f;
-  __syncthreads();
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (r < R && v < CV) {
     const uint16_t* xi = x + (long long)n * HW * C + v * 8;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = p_begin + r; p < p_end; p += 4 * R) {
       uint4 raw[4];
 #pragma unroll
@@ -35,74 +38,72 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
       for (int u = 0; u < 4; ++u) {
         if (p + u * R >= p_end) break;
         float f[8];
-        unpack8(raw[u], f);
+        unpack8t<F16>(raw[u], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
       }
     }
+  }
+  // row lanes meet in LDS and are added in row order by one thread per channel (fixed order)
+  if (r < R) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      atomicAdd(&lds[vl * 8 + e], s[e]);
-      atomicAdd(&lds[CVS * 8 + vl * 8 + e], q[e]);
-    }
+    for (int e = 0; e < 8; ++e) { lds[(r * 2) * CVS * 8 + vl * 8 + e] = s[e]; lds[(r * 2 + 1) * CVS * 8 + vl * 8 + e] = q[e]; }
   }
   __syncthreads();
-  double* st = stats + ((long long)n * C_total + c_off) * 2;
   for (int i = t; i < CVS * 8; i += 256) {
     const int c = blockIdx.z * CVS * 8 + i;
-    if (c < C) {
-      atomicAdd(&st[2 * c], (double)lds[i]);
-      atomicAdd(&st[2 * c + 1], (double)lds[CVS * 8 + i]);
+    if (c >= C) continue;
+    float a = 0.f, b = 0.f;
+    for (int rr = 0; rr < R; ++rr) { a += lds[(rr * 2) * CVS * 8 + i]; b += lds[(rr * 2 + 1) * CVS * 8 + i]; }
+    *reinterpret_cast<float2*>(part + (((long long)n * P + blockIdx.x) * C + c) * 2) = make_float2(a, b);
+  }
+}
+
+// ---- finalize: partial planes of one or two (virtually concatenated) sources -> per-(image, channel) affine (a, b) ----
+// grid = (G, N): one workgroup per (group, image) adds the group's cpg x P partial pairs in fp64 - per-thread in a fixed
+// strided order, then a fixed LDS tree - and writes a = rstd*gamma, b = beta - mean*a for its channels ([N][2][C]).
+// mean_out (optional, [N][G]): the group mean itself (G == C: AdaptiveAvgPool2d(1) of the tensor).
+__global__ void gn_finalize_kernel(const float* __restrict__ p1, int P1, int C1, const float* __restrict__ p2, int P2, int C2,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, int G, float eps,
+                                   double inv_cnt, float* __restrict__ ab, float* __restrict__ mean_out) {
+  __shared__ double red[2][256];
+  const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x, NT = blockDim.x;
+  const int C = C1 + C2, cpg = C / G, c_lo = g * cpg, Pmax = max(P1, P2);
+  double s = 0.0, q = 0.0;
+  for (int idx = t; idx < cpg * Pmax; idx += NT) {
+    const int p = idx / cpg, c = c_lo + (idx - p * cpg);
+    const bool first = c < C1;
+    const int P = first ? P1 : P2;
+    if (p < P) {
+      const float* src = first ? p1 + (((long long)n * P1 + p) * C1 + c) * 2 : p2 + (((long long)n * P2 + p) * C2 + (c - C1)) * 2;
+      const float2 v = *reinterpret_cast<const float2*>(src);
+      s += (double)v.x; q += (double)v.y;
     }
   }
+  red[0][t] = s; red[1][t] = q;
+  __syncthreads();
+  for (int o = NT >> 1; o > 0; o >>= 1) {
+    if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; }
+    __syncthreads();
+  }
+  const double mean = red[0][0] * inv_cnt;
+  const double var = fma(red[1][0], inv_cnt, -mean * mean);
+  const float rstd = rsqrtf(fmaxf((float)var, 0.f) + eps);
+  if (mean_out && t == 0) mean_out[(long long)n * G + g] = (float)mean;
+  if (ab)
+    for (int i = t; i < cpg; i += NT) {
+      const int c = c_lo + i;
+      const float a = rstd * (gamma ? gamma[c] : 1.f);
+      ab[((long long)n * 2) * C + c] = a;
+      ab[((long long)n * 2 + 1) * C + c] = (beta ? beta[c] : 0.f) - (float)mean * a;
+    }
 }
 
-// ---- GroupNorm pass 2 (tiny): per-image group statistics -> per-channel affine (a, b); re-zeroes the sums ----
-// grid = N, one block per image.  The fp64 sum buffer is zero at rest: this kernel consumes it and clears it, so
-// no zero-fill launch is needed per call.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(double* __restrict__ stats, float* __restrict__ ab,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          int HW, int C, int G, float eps, const double* __restrict__ pre1,
-                                                          const double* __restrict__ pre2, int C1) {
-  extern __shared__ double gl[];  // gsum[G], gsq[G], then (float) mean[G], rstd[G]
-  const int n = blockIdx.x, t = threadIdx.x, cpg = C / G;
-  double* st = stats + (long long)n * C * 2;
-  for (int g = t; g < 2 * G; g += 256) gl[g] = 0.0;
-  __syncthreads();
-  for (int c = t; c < C; c += 256) {                       // all threads, independent coalesced loads, LDS fp64 atomics
-    // channel c comes from the producer's fused sums (pre1 / pre2, read-only) or from this call's own pass (st)
-    const double* src = st + 2 * c;
-    bool own = true;
-    if (c < C1 && pre1) { src = pre1 + ((long long)n * C1 + c) * 2; own = false; }
-    if (c >= C1 && pre2) { src = pre2 + ((long long)n * (C - C1) + (c - C1)) * 2; own = false; }
-    const double s = src[0], q = src[1];
-    atomicAdd(&gl[c / cpg], s);
-    atomicAdd(&gl[G + c / cpg], q);
-    if (own) { st[2 * c] = 0.0; st[2 * c + 1] = 0.0; }     // leave the internal sums zero for the next call
-  }
-  __syncthreads();
-  float* mr = reinterpret_cast<float*>(gl + 2 * G);
-  for (int g = t; g < G; g += 256) {
-    const double cnt = (double)cpg * HW, mean = gl[g] / cnt;
-    double var = gl[G + g] / cnt - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    mr[g] = (float)mean;
-    mr[G + g] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
-  float* o = ab + (long long)n * C * 2;
-  for (int c = t; c < C; c += 256) {
-    const int g = c / cpg;
-    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f, a = mr[G + g] * ga;
-    o[c] = a;
-    o[C + c] = be - mr[g] * a;
-  }
-}
-
-// ---- GroupNorm pass 3: y = act(a[c]*x + b[c]) ------------------------------------------------------------------
+// ---- apply: y = act(a[c]*x + b[c]) ------------------------------------------------------------------------------------
 // Same (pixel chunk, image, channel slab) decomposition; each thread keeps its 8 channels' (a, b) in registers.
 // C = channels of THIS source tensor; it occupies channels [c_off, c_off+C) of the C_total-wide (virtually
 // concatenated) normalisation domain; y has row stride C_total.
+template <bool F16>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
                                                        const float* __restrict__ ab, int HW, int C, int silu,
                                                        int pix_per_block, int c_off, int C_total, int CVS) {
@@ -110,93 +111,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
   const int CV = C >> 3, R = 256 / CVS;
   const int r = t / CVS, v = blockIdx.z * CVS + (t - r * CVS);
   if (r >= R || v >= CV) return;
+  const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+  const uint16_t* xi = x + (long long)n * HW * C + v * 8;
+  uint4 raw[4];
+  if (p_begin + r < p_end) {            // first batch of loads issued ahead of the coefficient loads
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)min(p_begin + r + u * R, p_end - 1) * C);
+  }
   const float* abn = ab + (long long)n * C_total * 2 + c_off + v * 8;
   float a[8], b[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { a[e] = abn[e]; b[e] = abn[C_total + e]; }
-  const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
-  const uint16_t* xi = x + (long long)n * HW * C + v * 8;
-  uint16_t* yo = y + (long long)n * HW * C_total + c_off + v * 8;
-  for (int p = p_begin + r; p < p_end; p += 4 * R) {        // 4 independent 16-byte loads in flight per thread
-    uint4 raw[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pp = min(p + u * R, p_end - 1);
-      raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)pp * C);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pp = p + u * R;
-      if (pp >= p_end) break;
-      float f[8];
-      unpack8(raw[u], f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float o = f[e] * a[e] + b[e];
-        f[e] = silu ? silu_f(o) : o;
-      }
-      *reinterpret_cast<uint4*>(yo + (long long)pp * C_total) = pack8(f);
-    }
-  }
-}
-
-// ---- GroupNorm apply with the finalize folded in (all sources carry producer-side sums) -------------------------------
-// Each block rebuilds mean / rstd only for the groups its <=256-channel slab touches: cooperative fp64 LDS reduction over
-// those groups' channel sums, then the same streaming pass as gn_apply_kernel.  Saves one launch per GroupNorm.
-__global__ __launch_bounds__(256) void gn_apply_fused_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
-                                                             const double* __restrict__ pre1, const double* __restrict__ pre2,
-                                                             int C1, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, int HW, int C, int silu,
-                                                             int pix_per_block, int c_off, int C_total, int G, float eps, int CVS, double inv_cnt) {
-  __shared__ double gs[2][264];
-  __shared__ float gm[2][264];
-  const int n = blockIdx.y, t = threadIdx.x;
-  const int CV = C >> 3, R = 256 / CVS, cpg = C_total / G;
-  // this thread's pixels / channel vector; the first batch of loads is issued BEFORE the statistics prologue (independent of it)
-  const int r = t / CVS, v = blockIdx.z * CVS + (t - r * CVS);
-  const bool worker = r < R && v < CV;
-  const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
-  const uint16_t* xi = x + (long long)n * HW * C + (worker ? v : 0) * 8;
-  uint4 raw[4];
-  if (worker && p_begin + r < p_end) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(xi + (long long)min(p_begin + r + u * R, p_end - 1) * C);
-  }
-  // affine parameters of this thread's 8 channels: also issued ahead of the prologue (one global round trip less on its tail)
-  float ga[8], be[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = c_off + (worker ? v : 0) * 8 + e;
-    ga[e] = gamma ? gamma[c] : 1.f;
-    be[e] = beta ? beta[c] : 0.f;
-  }
-  const int cb = c_off + blockIdx.z * CVS * 8, ce = min(cb + CVS * 8, c_off + C);       // this slab in the C_total domain
-  const int g_lo = cb / cpg, g_hi = (ce - 1) / cpg, ng = g_hi - g_lo + 1;
-  for (int g = t; g < ng; g += 256) { gs[0][g] = 0.0; gs[1][g] = 0.0; }
-  __syncthreads();
-  const int C2 = C_total - C1;
-  for (int c = g_lo * cpg + t; c < (g_hi + 1) * cpg; c += 256) {
-    const double* src = c < C1 ? pre1 + ((long long)n * C1 + c) * 2 : pre2 + ((long long)n * C2 + (c - C1)) * 2;
-    atomicAdd(&gs[0][c / cpg - g_lo], src[0]);
-    atomicAdd(&gs[1][c / cpg - g_lo], src[1]);
-  }
-  __syncthreads();
-  for (int g = t; g < ng; g += 256) {
-    // mean / variance in fp64 (the subtraction cancels), 1/sqrt in fp32: inv_cnt comes from the host, so no fp64 divide / sqrt
-    const double mean = gs[0][g] * inv_cnt;
-    const double var = fma(gs[1][g], inv_cnt, -mean * mean);
-    gm[0][g] = (float)mean;
-    gm[1][g] = rsqrtf(fmaxf((float)var, 0.f) + eps);
-  }
-  __syncthreads();
-  if (!worker) return;
-  float a[8], b[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = c_off + v * 8 + e, g = c / cpg - g_lo;
-    a[e] = gm[1][g] * ga[e];
-    b[e] = be[e] - gm[0][g] * a[e];
-  }
   uint16_t* yo = y + (long long)n * HW * C_total + c_off + v * 8;
   for (int p = p_begin + r; p < p_end; p += 4 * R) {        // 4 independent 16-byte loads in flight per thread
     if (p != p_begin + r) {
@@ -211,19 +136,19 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const uint16_t* __r
       const int pp = p + u * R;
       if (pp >= p_end) break;
       float f[8];
-      unpack8(raw[u], f);
+      unpack8t<F16>(raw[u], f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float o = f[e] * a[e] + b[e];
         f[e] = silu ? silu_f(o) : o;
       }
-      *reinterpret_cast<uint4*>(yo + (long long)pp * C_total) = pack8(f);
+      *reinterpret_cast<uint4*>(yo + (long long)pp * C_total) = pack8t<F16>(f);
     }
   }
 }
 
 // ---- LayerNorm over C: one wave per row, R rows per wave in flight, exact two-pass variance in registers --------
-template <int VPL, int R>  // vectors (8 elems) per lane, rows batched per wave
+template <int VPL, int R, bool F16>  // vectors (8 elems) per lane, rows batched per wave; 16-bit type
 __global__ __launch_bounds__(256) void ln_rows_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       long long rows, int C, float eps) {
@@ -257,7 +182,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const uint16_t* __restrict
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
-      unpack8(raw[r][j], f[j]);
+      unpack8t<F16>(raw[r][j], f[j]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += f[j][e];
     }
@@ -277,13 +202,14 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const uint16_t* __restrict
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f[j][e] - mean) * rstd * ga[j][e] + be[j][e];
-        *reinterpret_cast<uint4*>(y + (row0 + r) * C + v * 8) = pack8(o);
+        *reinterpret_cast<uint4*>(y + (row0 + r) * C + v * 8) = pack8t<F16>(o);
       }
     }
   }
 }
 
 // ---- row softmax fp32 -> bf16 (one block per row; the row stays L2-resident across the 3 passes) ----
+template <bool F16>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, uint16_t* __restrict__ p, int cols,
                                                            int ldp) {
   __shared__ float red[8];
@@ -303,99 +229,140 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   __syncthreads();
   const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
   uint16_t* pr = p + row * ldp;
-  for (int i = t; i < cols; i += 256) pr[i] = f2bf(__expf(sr[i] - m) * inv);
+  for (int i = t; i < cols; i += 256) pr[i] = f2h16<F16>(__expf(sr[i] - m) * inv);
   for (int i = cols + t; i < ldp; i += 256) pr[i] = 0;
 }
 
 }  // namespace
 
-namespace ur {
-int gn_stats_launch(const void* x, double* stats, int N, int HW, int C, hipStream_t s) {
+// shared geometry of the statistics / apply passes: channel vectors per slab, slabs, pixel chunks, pixels per chunk
+static void gn_geom(int N, int HW, int C, int ppt, int& cvs, int& slabs, int& chunks, int& ppb) {
   const int cv = C / 8;
-  int cvs = cv < 32 ? cv : 32;
-  while (cv % cvs) --cvs;
-  const int slabs = cv / cvs, R = 256 / cvs;
-  long long want = std::max<long long>(1, 2048 / ((long long)N * slabs));
-  int chunks = (int)std::min<long long>(want, std::max(1, HW / (8 * R)));
-  const int ppb = (HW + chunks - 1) / chunks;
+  cvs = cv < 32 ? cv : 32;                               // channel vectors per slab (<= 256 channels):
+  while (cv % cvs) --cvs;                                // the largest divisor of CV that is <= 32 (no ragged slab)
+  slabs = cv / cvs;
+  const int R = 256 / cvs;
+  // aim for >= ~2048 blocks (8 per CU) but keep >= ppt pixel rows per thread when the tensor is big enough
+  static const int wantb = getenv("UR_GN_BLOCKS") ? atoi(getenv("UR_GN_BLOCKS")) : 2048;
+  const long long want = std::max<long long>(1, wantb / ((long long)N * slabs));
+  // (8x8 maps: 2 pixel rows per thread - 40 workgroups of 8-deep loops were pure latency)
+  chunks = (int)std::min<long long>(want, std::max(1, HW / ((HW <= 64 ? std::min(ppt, 2) : ppt) * R)));
+  ppb = (HW + chunks - 1) / chunks;
   chunks = (HW + ppb - 1) / ppb;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, N, slabs), dim3(256), 0, s, (const uint16_t*)x, stats, HW, C, ppb, 0, C, cvs);
+}
+
+namespace ur {
+int gn_stats_parts(int N, int HW, int C) {
+  int cvs, slabs, chunks, ppb;
+  gn_geom(N, HW, C, 8, cvs, slabs, chunks, ppb);
+  return chunks;
+}
+int gn_stats_launch(const void* x, float* part, int N, int HW, int C, int dtype, hipStream_t s) {
+  int cvs, slabs, chunks, ppb;
+  gn_geom(N, HW, C, 8, cvs, slabs, chunks, ppb);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(gn_stats_kernel<F16>, dim3(chunks, N, slabs), dim3(256), 0, s, (const uint16_t*)x, part, HW, C, ppb, cvs));
   return check_launch("gn_stats");
 }
 }  // namespace ur
 
 extern "C" {
 
-size_t ur_groupnorm_ws_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(double); }
+int ur_groupnorm_stats_parts(int N, int HW, int C) { return (N > 0 && HW > 0 && C > 0 && C % 8 == 0) ? ur::gn_stats_parts(N, HW, C) : UR_E_INVALID; }
+size_t ur_groupnorm_ws_bytes(int N, int HW, int C) { return (size_t)N * (size_t)std::max(ur_groupnorm_stats_parts(N, HW, C), 1) * C * 2 * sizeof(float); }
 size_t ur_groupnorm_ab_bytes(int N, int C) { return (size_t)N * C * 2 * sizeof(float); }
 
-int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int N, int HW,
-                      int C1, int C2, int G, float eps, int silu, void* ws, float* ab, const double* pre1, const double* pre2,
-                      ur_stream_t stream) {
-  UR_REQUIRE(x && y && ws && ab, "null pointer");
-  const int C = C1 + (x2 ? C2 : 0);
-  UR_REQUIRE(C1 % 8 == 0 && (!x2 || C2 % 8 == 0) && G > 0 && C % G == 0 && N > 0 && HW > 0, "C%8, C%G");
-  UR_REQUIRE((size_t)C * 8 <= 64 * 1024, "C too large");
+int ur_groupnorm_stats(const void* x, float* part, int N, int HW, int C, int dtype, ur_stream_t stream) {
+  UR_REQUIRE(x && part && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "bad args");
+  UR_REQUIRE_DT(dtype);
   hipStream_t s = (hipStream_t)stream;
-  const double bytes = 2.0 * N * HW * (double)C;
+  ur::ProfScope prof("groupnorm_stats", 0.0, 2.0 * N * HW * (double)C, s);
+  return ur::gn_stats_launch(x, part, N, HW, C, dtype, s);
+}
+int ur_instnorm_stats(const void* x, float* part, int N, int HW, int C, int dtype, ur_stream_t stream) {
+  return ur_groupnorm_stats(x, part, N, HW, C, dtype, stream);
+}
+
+int ur_groupnorm_finalize(const float* part1, int parts1, int C1, const float* part2, int parts2, int C2, const float* gamma,
+                          const float* beta, int N, int HW, int G, float eps, float* ab, float* mean_out, ur_stream_t stream) {
+  const int C = C1 + (part2 ? C2 : 0);
+  UR_REQUIRE(part1 && parts1 > 0 && C1 > 0 && (!part2 || (parts2 > 0 && C2 > 0)), "bad partial planes");
+  UR_REQUIRE(G > 0 && C % G == 0 && N > 0 && HW > 0 && (ab || mean_out), "bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const int cpg = C / G;
+  const long long entries = (long long)cpg * std::max(parts1, part2 ? parts2 : 0);
+  ur::ProfScope prof("groupnorm_finalize", 0.0, 8.0 * N * ((double)parts1 * C1 + (part2 ? (double)parts2 * C2 : 0.0)), s);
+  const int nt = entries <= 64 ? 64 : 256;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(nt), 0, s, part1, parts1, C1, part2, part2 ? parts2 : 0, part2 ? C2 : 0, gamma, beta, G,
+                     eps, 1.0 / ((double)cpg * HW), ab, mean_out);
+  return ur::check_launch("ur_groupnorm_finalize");
+}
+
+int ur_groupnorm_apply_act(const void* x, const void* x2, void* y, const float* ab, int N, int HW, int C1, int C2, int silu,
+                           int dtype, ur_stream_t stream) {
+  UR_REQUIRE(x && y && ab && N > 0 && HW > 0, "null pointer / empty");
+  UR_REQUIRE_DT(dtype);
+  const int C = C1 + (x2 ? C2 : 0);
+  UR_REQUIRE(C1 % 8 == 0 && (!x2 || C2 % 8 == 0), "C%8");
+  hipStream_t s = (hipStream_t)stream;
   const char* fam = "groupnorm";
   static const bool prof_shapes = getenv("UR_PROF_SHAPES") != nullptr;
-  if (prof_shapes) {                                     // per-shape families for tools/prof_shapes.py
+  if (prof_shapes) {                                     // per-shape families for offline analysis
     static std::map<std::string, int> interned;
     char buf[96];
-    snprintf(buf, sizeof buf, "gn N%d HW%d C%d+%d pre%d", N, HW, C1, x2 ? C2 : 0, (pre1 ? 1 : 0) + (x2 && pre2 ? 1 : 0));
+    snprintf(buf, sizeof buf, "gn N%d HW%d C%d+%d", N, HW, C1, x2 ? C2 : 0);
     fam = interned.emplace(buf, 0).first->first.c_str();
   }
-  ur::ProfScope prof(fam, 0.0, 3.0 * bytes, s);
-  // ws = [N][C][2] fp64 sums, ZERO AT REST (the caller zero-fills once, the finalize kernel re-zeroes what it read);
-  // ab = [N][2][C] fp32 affine table (plain scratch; separate so it can never alias another call's sums)
-  double* stats = (double*)ws;
+  ur::ProfScope prof(fam, 0.0, 4.0 * N * HW * (double)C, s);
   const uint16_t* src[2] = {(const uint16_t*)x, (const uint16_t*)x2};
   const int cs[2] = {C1, x2 ? C2 : 0}, off[2] = {0, C1};
-  int chunks[2], ppb[2], cvs[2], slabs[2];
+  static const int ppt = getenv("UR_GN_PPT") ? atoi(getenv("UR_GN_PPT")) : 8;
   for (int i = 0; i < 2; ++i) {
     if (cs[i] <= 0) continue;
-    const int cv = cs[i] / 8;
-    cvs[i] = cv < 32 ? cv : 32;                            // channel vectors per slab (<= 256 channels):
-    while (cv % cvs[i]) --cvs[i];                          // the largest divisor of CV that is <= 32 (no ragged slab)
-    slabs[i] = (cv + cvs[i] - 1) / cvs[i];
-    const int R = 256 / cvs[i];
-    // aim for >= ~2048 blocks (8 per CU) but keep >= 4 pixel rows per thread when the tensor is big enough
-    long long want = std::max<long long>(1, 2048 / ((long long)N * slabs[i]));
-    static const int ppt = getenv("UR_GN_PPT") ? atoi(getenv("UR_GN_PPT")) : 8;
-    static const int wantb = getenv("UR_GN_BLOCKS") ? atoi(getenv("UR_GN_BLOCKS")) : 2048;
-    want = std::max<long long>(1, wantb / ((long long)N * slabs[i]));
-    // (8x8 maps: 2 pixel rows per thread - 40 workgroups of 8-deep loops were pure latency)
-    chunks[i] = (int)std::min<long long>(want, std::max(1, HW / ((HW <= 64 ? std::min(ppt, 2) : ppt) * R)));
-    ppb[i] = (HW + chunks[i] - 1) / chunks[i];
-    chunks[i] = (HW + ppb[i] - 1) / ppb[i];
-    const double* pre = i == 0 ? pre1 : pre2;
-    if (!pre)
-      hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], stats, HW, cs[i], ppb[i], off[i],
-                         C, cvs[i]);
+    int cvs, slabs, chunks, ppb;
+    gn_geom(N, HW, cs[i], ppt, cvs, slabs, chunks, ppb);
+    UR_DT_SWITCH(dtype, hipLaunchKernelGGL(gn_apply_kernel<F16>, dim3(chunks, N, slabs), dim3(256), 0, s, src[i], (uint16_t*)y, ab, HW, cs[i], silu,
+                                           ppb, off[i], C, cvs));
   }
-  const bool all_pre = pre1 && (!x2 || pre2);
-  const int cpg = C / G;
-  if (all_pre && (256 / cpg + 2) <= 264) {
-    for (int i = 0; i < 2; ++i)
-      if (cs[i] > 0)
-        hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], (uint16_t*)y, pre1,
-                           x2 ? pre2 : nullptr, C1, gamma, beta, HW, cs[i], silu, ppb[i], off[i], C, G, eps, cvs[i], 1.0 / ((double)cpg * HW));
-    return ur::check_launch("ur_groupnorm_nhwc");
+  return ur::check_launch("ur_groupnorm_apply_act");
+}
+
+int ur_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int N, int HW,
+                      int C1, int C2, int G, float eps, int silu, float* ws, float* ab, const float* pre1, int parts1,
+                      const float* pre2, int parts2, int dtype, ur_stream_t stream) {
+  UR_REQUIRE(x && y && ab, "null pointer");
+  UR_REQUIRE((pre1 && (!x2 || pre2)) || ws, "a source without producer-side partials needs the ws scratch");
+  // statistics pass only for sources whose producer left no partial plane (ws holds x's plane, then x2's)
+  if (!pre1) {
+    parts1 = ur::gn_stats_parts(N, HW, C1);
+    int rc = ur_groupnorm_stats(x, ws, N, HW, C1, dtype, stream);
+    if (rc != UR_OK) return rc;
+    pre1 = ws;
+    ws += (size_t)N * parts1 * C1 * 2;
   }
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), (size_t)G * (2 * sizeof(double) + 2 * sizeof(float)), s, stats, ab,
-                     gamma, beta, HW, C, G, eps, pre1, x2 ? pre2 : nullptr, C1);
-  for (int i = 0; i < 2; ++i)
-    if (cs[i] > 0)
-      hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks[i], N, slabs[i]), dim3(256), 0, s, src[i], (uint16_t*)y, ab, HW, cs[i], silu,
-                         ppb[i], off[i], C, cvs[i]);
-  return ur::check_launch("ur_groupnorm_nhwc");
+  if (x2 && !pre2) {
+    parts2 = ur::gn_stats_parts(N, HW, C2);
+    int rc = ur_groupnorm_stats(x2, ws, N, HW, C2, dtype, stream);
+    if (rc != UR_OK) return rc;
+    pre2 = ws;
+  }
+  int rc = ur_groupnorm_finalize(pre1, parts1, C1, x2 ? pre2 : nullptr, parts2, C2, gamma, beta, N, HW, G, eps, ab, nullptr, stream);
+  if (rc != UR_OK) return rc;
+  return ur_groupnorm_apply_act(x, x2, y, ab, N, HW, C1, C2, silu, dtype, stream);
+}
+
+/* mean over HW -> fp32 [N][C] (nn.AdaptiveAvgPool2d(1)): the statistics pass + a finalize with one group per channel */
+int ur_avgpool_hw(const void* x, float* out, int N, int HW, int C, float* ws, int dtype, ur_stream_t stream) {
+  UR_REQUIRE(x && out && ws && C % 8 == 0, "bad args");
+  int rc = ur_groupnorm_stats(x, ws, N, HW, C, dtype, stream);
+  if (rc != UR_OK) return rc;
+  return ur_groupnorm_finalize(ws, ur::gn_stats_parts(N, HW, C), C, nullptr, 0, 0, nullptr, nullptr, N, HW, C, 0.f, nullptr, out, stream);
 }
 
 int ur_layernorm_rows(const void* x, void* y, const float* gamma, const float* beta, long long rows, int C, float eps,
-                      ur_stream_t stream) {
+                      int dtype, ur_stream_t stream) {
   UR_REQUIRE(x && y && rows > 0, "null pointer / empty");
   UR_REQUIRE(C % 8 == 0 && C <= 2048, "C%8 and C<=2048");
+  UR_REQUIRE_DT(dtype);
   hipStream_t s = (hipStream_t)stream;
   ur::ProfScope prof("layernorm", 0.0, 4.0 * rows * (double)C, s);
   const int vpl = (C / 8 + 63) / 64;
@@ -404,19 +371,19 @@ int ur_layernorm_rows(const void* x, void* y, const float* gamma, const float* b
   const uint16_t* xi = (const uint16_t*)x;
   uint16_t* yo = (uint16_t*)y;
   switch (vpl) {
-    case 1: hipLaunchKernelGGL((ln_rows_kernel<1, R>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
-    case 2: hipLaunchKernelGGL((ln_rows_kernel<2, R>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
-    case 3: hipLaunchKernelGGL((ln_rows_kernel<3, R>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
-    default: hipLaunchKernelGGL((ln_rows_kernel<4, R>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps); break;
+    case 1: UR_DT_SWITCH(dtype, hipLaunchKernelGGL((ln_rows_kernel<1, R, F16>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps)); break;
+    case 2: UR_DT_SWITCH(dtype, hipLaunchKernelGGL((ln_rows_kernel<2, R, F16>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps)); break;
+    case 3: UR_DT_SWITCH(dtype, hipLaunchKernelGGL((ln_rows_kernel<3, R, F16>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps)); break;
+    default: UR_DT_SWITCH(dtype, hipLaunchKernelGGL((ln_rows_kernel<4, R, F16>), grid, block, 0, s, xi, yo, gamma, beta, rows, C, eps)); break;
   }
   return ur::check_launch("ur_layernorm_rows");
 }
 
-int ur_softmax_rows_f32(const float* sm, void* p, long long rows, int cols, int ldp, ur_stream_t stream) {
+int ur_softmax_rows_f32(const float* sm, void* p, long long rows, int cols, int ldp, int dtype, ur_stream_t stream) {
   UR_REQUIRE(sm && p && rows > 0 && cols > 0 && ldp >= cols, "bad args");
   hipStream_t s = (hipStream_t)stream;
   ur::ProfScope prof("softmax_rows", 0.0, rows * (double)cols * 6.0, s);
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, sm, (uint16_t*)p, cols, ldp);
+  UR_DT_SWITCH(dtype, hipLaunchKernelGGL(softmax_rows_kernel<F16>, dim3((unsigned)rows), dim3(256), 0, s, sm, (uint16_t*)p, cols, ldp));
   return ur::check_launch("ur_softmax_rows_f32");
 }
 

@@ -52,6 +52,49 @@ def broadcast_weights(model: torch.nn.Module, src: int = 0, bucket_bytes: int = 
     return moved
 
 
+def broadcast_weights_sharded(model: torch.nn.Module, src: int = 0, bucket_bytes: int = 512 << 20) -> int:
+    """Weight broadcast as SCATTER + ALL-GATHER: xGMI is a full mesh of point-to-point links, so a
+    rooted broadcast is bound by the root's links; here the root sends each rank only 1/world of a bucket (scatter) and every
+    rank then forwards its slice to all others (all-gather) - every link carries 1/world of the bytes, all links busy.
+    Same result as `broadcast_weights`; returns the number of payload bytes."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    tensors: List[torch.Tensor] = [p.data for p in model.parameters()] + [b for b in model.buffers()]
+    moved = 0
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), ts in by_dtype.items():
+        esize = torch.empty((), dtype=dtype).element_size()
+        bucket, size = [], 0
+
+        def flush():
+            nonlocal bucket, size, moved
+            if not bucket:
+                return
+            n = sum(t.numel() for t in bucket)
+            per = (n + world - 1) // world
+            flat = torch.zeros(per * world, dtype=dtype, device=device)
+            if rank == src:
+                torch.cat([t.reshape(-1) for t in bucket], out=flat[:n])
+            mine = torch.empty(per, dtype=dtype, device=device)
+            dist.scatter(mine, [flat[r * per:(r + 1) * per] for r in range(world)] if rank == src else None, src=src)
+            dist.all_gather_into_tensor(flat, mine)
+            off = 0
+            for t in bucket:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+            moved += n * esize
+            bucket, size = [], 0
+
+        for t in ts:
+            bucket.append(t)
+            size += t.numel() * esize
+            if size >= bucket_bytes:
+                flush()
+        flush()
+    return moved
+
+
 def all_gather_images(shard: torch.Tensor, sizes: List[int] = None) -> torch.Tensor:
     """Gather per-rank [b_r, C, H, W] shards into [sum b_r, C, H, W] on every rank (rank order = batch order)."""
     world = dist.get_world_size()

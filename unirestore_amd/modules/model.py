@@ -59,9 +59,12 @@ class Controller(nn.Module):
                 nn.init.zeros_(m.to_out[0].weight), nn.init.zeros_(m.to_out[0].bias)
 
     def set_timesteps(self, timesteps):
+        """(Re)build the per-resnet time-embedding bias tables.  Bumps `table_epoch`: an owning DiffUIE sees that its own
+        schedule tables (and every graph captured against their addresses) are stale and rebuilds them."""
         emb = self.time_embedding.silu_emb(sinusoid_table(timesteps, self.model_channels))
         for r in _resnets(self):
             r.set_time_table(emb)
+        self.table_epoch = getattr(self, "table_epoch", 0) + 1
 
     def stem(self, z_bf16):
         """conv_in(z0) does not depend on t: computed once per image, reused by every step (controller.py:198)."""
@@ -91,8 +94,8 @@ class Controller(nn.Module):
         b = stem.shape[0]
         x = stem.repeat(nsteps, 1, 1, 1)
         g = ops.gn_of(stem)
-        if g is not None:
-            x._gn = g.view(b, -1).repeat(nsteps, 1).view(-1)
+        if g is not None:                                  # the partial statistics repeat with the images
+            x._gn = (g[0].repeat(nsteps, 1, 1, 1), g[1])
         out = self.run(x, "all")
         return [{k: v[i * b:(i + 1) * b] for k, v in out.items()} for i in range(nsteps)]
 
@@ -102,7 +105,6 @@ class Controller(nn.Module):
         if len(set(ts)) != 1:
             raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
         self.set_timesteps(ts[:1])
-        ops.arena().reset()
         out = self.run(self.stem(ops.nchw_to_nhwc(x.to(DEV))), 0)
         return {k: ops.nhwc_to_nchw(v) for k, v in out.items()}
 
@@ -138,11 +140,13 @@ class ControlledUNet(nn.Module):
         emb = u.time_embedding.silu_emb(sinusoid_table(timesteps, u.time_proj_dim))
         for r in _resnets(u):
             r.set_time_table(emb)
+        self.table_epoch = getattr(self, "table_epoch", 0) + 1          # see Controller.set_timesteps
 
     def _ctx(self):
-        if "ctx" not in self.__dict__:
-            self.__dict__["ctx"] = self.null_embeds.to(DEV, ops.BF16).contiguous()
-        return self.__dict__["ctx"]
+        key = ("ctx", ops.act_dtype())
+        if key not in self.__dict__:
+            self.__dict__[key] = self.null_embeds.to(DEV, ops.act_dtype()).contiguous()
+        return self.__dict__[key]
 
     def run(self, zt_bf16, control, step):
         """zt_bf16 [B,h,w,8] (latent channels zero-padded), control {width: NHWC bf16} -> eps fp32 [B,h,w,8]."""
@@ -203,7 +207,6 @@ class ControlledUNet(nn.Module):
         if len(set(ts)) != 1:
             raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
         self.set_timesteps(ts[:1])
-        ops.arena().reset()
         ctl = {k: ops.nchw_to_nhwc(v.to(DEV)) for k, v in control.items()}
         eps = self.run(ops.nchw_to_nhwc(sample.to(DEV)), ctl, 0)
         return ops.nhwc_to_nchw(eps, c=self.unet.conv_out.out_channels)
@@ -255,20 +258,24 @@ class SkipConnectedAutoEncoder(nn.Module):
     def decode_run(self, z_f32: torch.Tensor, res_samples, task: str, out_plan=None):
         """out_plan = (crop_hw, out_hw, quantize): un-pad + bicubic resize back (+ 8-bit quantisation) in the layout kernel."""
         dec, lat = self.vae.decoder, self.vae.latent_channels
-        if task not in dec.task_prompts:
+        if self.tedit_dict and task not in dec.task_prompts:
             raise KeyError(task)
         zb = ops.f32_to_bf16(z_f32, lat, mul=1.0 / self.vae.config.scaling_factor)
         h = ops.conv(ops.conv(zb, self.vae.post_quant_conv.packed()), dec.conv_in.packed(), gn=True)
         h = dec.mid_block.run(h)
-        b = z_f32.shape[0]
-        key = ("cache", "prompt", task)
-        if key not in self.__dict__:                           # device copy made once (not inside graph capture)
-            self.__dict__[key] = dec.task_prompts[task].detach().float().to(DEV)
-        cond = self.__dict__[key].unsqueeze(0).expand(b, -1, -1).contiguous()
-        for i, blk in enumerate(dec.up_blocks[:-1]):
-            h, cond = dec.task_editors[i].run(h, res_samples[-i - 1], cond)
-            h = blk.run(h)
-        h = dec.up_blocks[-1].run(h)
+        if not self.tedit_dict:                                # stock VAE decoder: the reference only patches the decoder
+            for blk in dec.up_blocks:                          # forward when a task editor is configured (autoencoder.py:107-110)
+                h = blk.run(h)
+        else:
+            b = z_f32.shape[0]
+            key = ("cache", "prompt", task)
+            if key not in self.__dict__:                       # device copy made once (not inside graph capture)
+                self.__dict__[key] = dec.task_prompts[task].detach().float().to(DEV)
+            cond = self.__dict__[key].unsqueeze(0).expand(b, -1, -1).contiguous()
+            for i, blk in enumerate(dec.up_blocks[:-1]):
+                h, cond = dec.task_editors[i].run(h, res_samples[-i - 1], cond)
+                h = blk.run(h)
+            h = dec.up_blocks[-1].run(h)
         h = ops.conv(dec.conv_norm_out.run(h, silu=True), dec.conv_out.packed(), out_f32=True)
         if out_plan:
             return ops.image_unpad_resize(h, dec.conv_out.out_channels, out_plan[0], out_plan[1], mul=0.5, add=0.5, quantize=out_plan[2])
@@ -277,7 +284,6 @@ class SkipConnectedAutoEncoder(nn.Module):
     # ---- reference signatures ---------------------------------------------------------------------------------
     def encode(self, images, enable_fr: bool = False, noise=None):
         images = images.to(DEV).float()
-        ops.arena().reset()
         b, _, hh, ww = images.shape
         if noise is None:
             noise = torch.randn(b, self.vae.latent_channels, hh // 8, ww // 8, device=DEV)
@@ -285,7 +291,6 @@ class SkipConnectedAutoEncoder(nn.Module):
         return ops.nhwc_to_nchw(z, c=self.vae.latent_channels), [ops.nhwc_to_nchw(r) for r in res]
 
     def decode(self, latents, res_samples, task: str):
-        ops.arena().reset()
         z = ops.nchw_to_nhwc(latents.to(DEV)).float()
         return self.decode_run(z.contiguous(), [ops.nchw_to_nhwc(r.to(DEV)) for r in res_samples], task)
 
@@ -306,8 +311,12 @@ class DiffUIE(nn.Module):
     """forward(images, task) -> restored images, same contract as the reference (fp32 NCHW in [0,1])."""
 
     def __init__(self, frenc: Optional[dict] = None, cnet: Optional[dict] = None, tedit: Optional[dict] = None, *,
-                 unet_cfg=None, vae_cfg=None, controller_cfg=None, null_embeds=None, fr_depths=(1, 1, 9), use_graph=True):
+                 unet_cfg=None, vae_cfg=None, controller_cfg=None, null_embeds=None, fr_depths=(1, 1, 9), use_graph=True,
+                 dtype="bf16"):
+        """dtype: "bf16" (the reference's bf16-mixed precision) or "fp16" - the 16-bit type activations and weights are
+        stored in and fed to the matrix cores; accumulation, statistics, softmax and the DDIM state are fp32 in both."""
         super().__init__()
+        self.dtype = ops.set_dtype(dtype)
         self.fr_type = frenc["type"] if frenc else None
         self.control_type = cnet["type"] if cnet else None
         self.tedit = tedit if tedit else None
@@ -324,6 +333,20 @@ class DiffUIE(nn.Module):
             self.num_inference_steps = int(cnet["num_inference_steps"])
             self.timesteps = schedule.ddim_timesteps(self.num_inference_steps)       # host int64, bit-exact
             self._tables_ready = False
+            self._table_epochs = None
+
+    def set_num_inference_steps(self, n: int):
+        """Change the DDIM schedule length (`cnet.num_inference_steps`, unifie.py:70-75): tables and graphs are rebuilt lazily."""
+        self.num_inference_steps = int(n)
+        self.timesteps = schedule.ddim_timesteps(self.num_inference_steps)
+        self._tables_ready = False
+        return self
+
+    def set_dtype(self, dtype):
+        """Switch the 16-bit compute type; packed weights are kept per type, captured graphs are dropped."""
+        self.dtype = ops.set_dtype(dtype)
+        self._graphs.clear()
+        return self
 
     # ---- weights ------------------------------------------------------------------------------------------------
     def load_state_dict(self, *a, **k):
@@ -334,18 +357,27 @@ class DiffUIE(nn.Module):
     def refresh(self):
         """Drop device copies derived from the fp32 masters (after loading / editing weights)."""
         invalidate_packed(self)
-        self.base_model.__dict__.pop("ctx", None) if self.control_type else None
         self._tables_ready = False
         self._graphs.clear()
 
     def _prepare(self):
-        if self.control_type and not self._tables_ready:
+        ops.set_dtype(self.dtype)
+        if not self.control_type:
+            return
+        # The schedule's bias tables belong to the resnets; an ad-hoc Controller.forward / ControlledUNet.forward /
+        # predict_z0 call rebinds them (table_epoch moves).  Graphs captured against the old tables hold dangling addresses:
+        # rebuild the tables and drop the graphs whenever the epochs are not the ones this object last set.
+        epochs = (getattr(self.controller, "table_epoch", 0), getattr(self.base_model, "table_epoch", 0))
+        if not self._tables_ready or epochs != self._table_epochs:
+            self._graphs.clear()
             self.controller.set_timesteps(self.timesteps)
             self.base_model.set_timesteps(self.timesteps)
+            self._table_epochs = (self.controller.table_epoch, self.base_model.table_epoch)
             self._tables_ready = True
 
     # ---- reference helper signatures ------------------------------------------------------------------------------
     def diffuse(self, latents, timesteps=None, noise=None):
+        ops.set_dtype(self.dtype)
         latents = latents.to(DEV).float()
         if timesteps is None:
             timesteps = self.train_timesteps[torch.randint(0, len(self.train_timesteps), (latents.size(0),))]
@@ -365,7 +397,6 @@ class DiffUIE(nn.Module):
         Returns (preds NCHW fp32 at the original size, z0, zt) (NHWC fp32 latents)."""
         lat = self.ae.vae.latent_channels
         h, w, pad_h, pad_w = plan
-        ops.arena(images.device).reset()             # zero the fused GroupNorm sums of the previous forward (one fill)
         z0, z0b, mids = self.ae.encode_run(images, n_vae, enable_fr=self.fr_type is not None, plan=plan)
         zt = z0
         if self.control_type:
@@ -373,10 +404,7 @@ class DiffUIE(nn.Module):
             zt, ztb = ops.add_noise(z0, n_t, lat, float(np.float32(ac[999] ** 0.5)), float(np.float32((1 - ac[999]) ** 0.5)))
             stem = self.controller.stem(z0b)
             controls = self.controller.run_schedule(stem, len(self.timesteps)) if self.batch_controller else None
-            arena = ops.arena(images.device)
-            mark = arena.mark()
             for i, t in enumerate(self.timesteps):
-                arena.rewind(mark)                       # per-step GroupNorm sums reuse one region (re-zeroed per step)
                 control = controls[i] if controls is not None else self.controller.run(stem, i)
                 eps = self.base_model.run(ztb, control, i)
                 c_x, c_e = schedule.ddim_coefficients(int(t), self.num_inference_steps)
@@ -391,6 +419,7 @@ class DiffUIE(nn.Module):
         Resize / reflect pad / un-pad / resize back (unifie.py:124-134,164-168) run as HIP kernels inside the graph."""
         if task not in self.ae.task_list and self.tedit:
             raise KeyError(task)
+        self._prepare()
         images = images.to(DEV).float().contiguous()
         org_h, org_w = images.shape[-2:]
         plan = resize_pad_plan(org_h, org_w)
@@ -402,7 +431,6 @@ class DiffUIE(nn.Module):
         n_vae, n_t = (n.to(DEV).float().contiguous() for n in noise)
         if tuple(n_vae.shape) != (b, lat, lh, lw) or tuple(n_t.shape) != (b, lat, lh, lw):
             raise ValueError(f"noise must be two tensors of shape {(b, lat, lh, lw)}")
-        self._prepare()
         if self.use_graph:
             preds, z0, zt = self._graph_forward(images, task, n_vae, n_t, plan, quantize)
         else:
@@ -413,7 +441,7 @@ class DiffUIE(nn.Module):
 
     # ---- hipGraph: the whole fixed-length forward (encode, N denoise steps, decode) is one captured graph --------------
     def _graph_forward(self, images, task, n_vae, n_t, plan, quantize=False):
-        key = (tuple(images.shape), task, bool(quantize))
+        key = (tuple(images.shape), task, bool(quantize), self.dtype)
         g = self._graphs.get(key)
         if g is None:
             static = dict(images=images.clone(), n_vae=n_vae.clone(), n_t=n_t.clone())
@@ -439,18 +467,19 @@ class DiffUIE(nn.Module):
         graph.replay()
         if os.environ.get("UR_DEBUG_SYNC"):
             torch.cuda.synchronize()
-        return outs
+        # the graph's output tensors are overwritten by the next replay of this (shape, task) graph: hand the caller copies
+        # (runner.forward keeps [enh_hq, enh_lq] of two same-shape calls; a copy is tiny next to a forward)
+        return tuple(o.clone() for o in outs)
 
     def predict_z0(self, latents, conditions, timesteps):
         """unifie.py:91-105 (training-side helper): per-sample timesteps via per-image bias rows."""
+        ops.set_dtype(self.dtype)
         lat = latents.shape[1]
         ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
         if len(ts) == 1:
             ts = ts * latents.shape[0]
-        self.controller.set_timesteps(ts)
-        self.base_model.set_timesteps(ts)
-        self._tables_ready = False
-        ops.arena().reset()
+        self.controller.set_timesteps(ts)             # bumps the table epochs: the next forward() rebuilds the schedule tables
+        self.base_model.set_timesteps(ts)             # and drops its graphs (see _prepare)
         zb = ops.nchw_to_nhwc(latents.to(DEV))
         cb = ops.nchw_to_nhwc(conditions.to(DEV))
         outs = []

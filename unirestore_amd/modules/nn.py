@@ -32,7 +32,7 @@ class _NoEager:
 
 class Conv2d(_NoEager, nn.Conv2d):
     def packed(self, pair=False, scale: Optional[torch.Tensor] = None) -> ops.PackedConv:
-        key = ("pk", pair)
+        key = ("pk", pair, ops.act_dtype())           # device copies are per 16-bit type
         if key not in self.__dict__:
             w, b = self.weight, self.bias
             if scale is not None:                     # fold a per-output-channel scale (NAFBlock beta/gamma)
@@ -45,7 +45,7 @@ class Conv2d(_NoEager, nn.Conv2d):
 
 class Linear(_NoEager, nn.Linear):
     def packed(self, pair=False) -> ops.PackedConv:
-        key = ("pk", pair)
+        key = ("pk", pair, ops.act_dtype())
         if key not in self.__dict__:
             self.__dict__[key] = ops.pack_conv(self.weight, self.bias, DEV, pair=pair)
         return self.__dict__[key]
@@ -70,6 +70,11 @@ class GroupNorm(_NoEager, _Affine, nn.GroupNorm):
         g, b = self.dev()
         return ops.group_norm(x, g, b, self.num_groups, self.eps, silu, x2=x2)
 
+    def coeffs(self, x, x2=None):
+        """fp32 ab [N][2][C]: GroupNorm(x | x2) == a*x + b per (image, channel) - for a consumer that applies it itself."""
+        g, b = self.dev()
+        return ops.gn_finalize(x, g, b, self.num_groups, self.eps, x2=x2)
+
 
 class LayerNorm(_NoEager, _Affine, nn.LayerNorm):
     def run(self, x):
@@ -80,8 +85,8 @@ class LayerNorm(_NoEager, _Affine, nn.LayerNorm):
 def invalidate_packed(model: nn.Module):
     """Drop every cached device copy (call after loading new weights)."""
     for m in model.modules():
-        for k in [k for k in m.__dict__ if k in ("aff", "f32", "dw", "vecs", "fused", "ctx", "gb") or
-                  (isinstance(k, tuple) and k[0] in ("pk", "cache"))]:
+        for k in [k for k in m.__dict__ if k in ("aff", "f32", "dw", "vecs") or
+                  (isinstance(k, tuple) and k[0] in ("pk", "cache", "fused", "ctx", "gb"))]:
             del m.__dict__[k]
 
 
@@ -138,7 +143,6 @@ class ResnetBlock2D(nn.Module):
         """x (+x2: virtual concat) NHWC bf16.  step: row of the time table, or "all" when the batch stacks every step of
         the schedule (step-major); sample_bias: explicit [N,cout] per-image rows; control: {width: NHWC map} for a grafted
         SPADE (base_model.py:56-92)."""
-        h = self.norm1.run(x, silu=True, x2=x2)
         bias = None
         if self.time_emb_proj is not None:
             if sample_bias is not None:
@@ -147,8 +151,8 @@ class ResnetBlock2D(nn.Module):
                 bias = self._tbias_all(x.shape[0] // self.tbias.shape[0])
             else:
                 bias = self.tbias[step]
-        h = ops.conv(h, self.conv1.packed(), bias=bias, gn=True)
-        h = self.norm2.run(h, silu=True)
+        h = gn_silu_conv(self.norm1, x, self.conv1.packed(), x2=x2, bias=bias, gn=True)
+        pc2 = self.conv2.packed()
         if self.conv_shortcut is not None:    # (tried as a parallel graph branch at the low-resolution levels: fork/join cost more than it hid)
             sc = ops.conv(x, self.conv_shortcut.packed(), x2=x2)
         else:
@@ -156,9 +160,21 @@ class ResnetBlock2D(nn.Module):
         if control is not None and "spade" in self._modules:
             if x2 is not None and self.conv_shortcut is None:
                 raise ValueError("identity shortcut cannot take a virtual concat")
-            h = ops.conv(h, self.conv2.packed(), gn=True)
+            h = gn_silu_conv(self.norm2, h, pc2, gn=True)
             return self.spade.run(h, control[h.shape[2]], residual=sc)          # (no fused sums: the next norm takes its own)
-        return ops.conv(h, self.conv2.packed(), residual=sc, gn=True)
+        return gn_silu_conv(self.norm2, h, pc2, residual=sc, gn=True)
+
+
+FUSE_GN = os.environ.get("UR_FUSE_GN", "1") == "1"       # GroupNorm apply + SiLU inside the consuming 3x3 conv's loader
+
+
+def gn_silu_conv(norm: "GroupNorm", x, pc, x2=None, **kw):
+    """conv(SiLU(GroupNorm(x | x2))): statistics -> per-(image, channel) affine, then either the conv applies it while it
+    loads its input patch (no normalised tensor in HBM) or, where the launch cannot, a separate apply pass runs first."""
+    ab = norm.coeffs(x, x2=x2)
+    if FUSE_GN and ops.conv_plan(x, pc, x2=x2, gn=kw.get("gn", False), gn_ab=True, residual=kw.get("residual") is not None).prologue_ok:
+        return ops.conv(x, pc, x2=x2, gn_ab=ab, gn_silu=True, **kw)
+    return ops.conv(ops.gn_apply(x, ab, silu=True, x2=x2), pc, **kw)
 
 
 class Downsample2D(nn.Module):
@@ -190,18 +206,19 @@ class _ToOut(nn.ModuleList):
 
 
 def _fused_qkv(mod, names):
-    if ("cache", "qkv") not in mod.__dict__:
+    ck = ("cache", "qkv", ops.act_dtype())
+    if ck not in mod.__dict__:
         ws = [getattr(mod, n).weight for n in names]
         bs = [getattr(mod, n).bias for n in names]
         w = torch.cat([t.detach().float() for t in ws], 0)
         b = None if bs[0] is None else torch.cat([t.detach().float() for t in bs], 0)
-        mod.__dict__[("cache", "qkv")] = ops.pack_conv(w, b, DEV)
-    return mod.__dict__[("cache", "qkv")]
+        mod.__dict__[ck] = ops.pack_conv(w, b, DEV)
+    return mod.__dict__[ck]
 
 
 def _fused_ln(mod, key, names, norm, pair=False):
     """Linear(LayerNorm(x)) weights folded for the LN-fused GEMM epilogue (cached): rows = cat of `names`."""
-    ck = ("cache", "ln", key)
+    ck = ("cache", "ln", key, ops.act_dtype())
     if ck not in mod.__dict__:
         ws = [getattr(mod, n).weight.detach().float() for n in names]
         bs = [getattr(mod, n).bias for n in names]
@@ -218,8 +235,8 @@ def self_attention(mod, h, heads, residual, gn_kw={}, ln=None, rows=False):
     b, t, c = h.shape
     d = c // heads
     ldvt = ops.round_up(t, 8)
-    vt = torch.zeros((b, c, ldvt), dtype=ops.BF16, device=h.device) if ldvt != t else \
-        torch.empty((b, c, ldvt), dtype=ops.BF16, device=h.device)
+    vt = torch.zeros((b, c, ldvt), dtype=h.dtype, device=h.device) if ldvt != t else \
+        torch.empty((b, c, ldvt), dtype=h.dtype, device=h.device)
     if ln is not None:
         qk = ops.linear(h, _fused_ln(mod, "qkv", ("to_q", "to_k", "to_v"), ln[0]), ln_stats=ln[1], yt=vt, n_split=2 * c, t_rows=t)
     else:
@@ -272,12 +289,12 @@ class CrossAttention(nn.Module):
 
     def context_kv(self, ctx: torch.Tensor):
         """K [Tk,C] and V^T [C,ldvt] of the (constant) context, computed once (base_model.py:23-27,221)."""
-        key = ("cache", "ctx")
+        key = ("cache", "ctx", ops.act_dtype())
         if key not in self.__dict__:
             tk = ctx.shape[1]
             c = self.to_q.out_features
             kv = _fused_qkv(self, ("to_k", "to_v"))
-            vt = torch.zeros((1, c, ops.round_up(tk, 8)), dtype=ops.BF16, device=DEV)
+            vt = torch.zeros((1, c, ops.round_up(tk, 8)), dtype=ctx.dtype, device=DEV)
             k = ops.linear(ctx, kv, yt=vt, n_split=c, t_rows=tk)      # [1,Tk,2C]; K = first C columns
             self.__dict__[key] = (k, vt, tk)
         return self.__dict__[key]

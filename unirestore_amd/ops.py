@@ -10,11 +10,39 @@ from typing import Optional
 import torch
 
 from . import capi
-from .capi import (UR_ACT_GATE, UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_RELU, UR_ACT_SILU, UR_ACT_TANH, ConvDesc,
-                   check, lib)
+from .capi import (UR_ACT_GATE, UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_RELU, UR_ACT_SILU, UR_ACT_TANH, UR_DT_BF16,
+                   UR_DT_F16, ConvDesc, ConvPlan, check, lib)
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 _ws = {}
+
+# ---- compute dtype: the 16-bit type activations / weights are stored in and fed to the matrix cores ----------------------
+_DTYPES = {"bf16": BF16, "bfloat16": BF16, BF16: BF16, "fp16": F16, "float16": F16, "f16": F16, "16": F16, F16: F16}
+_act = BF16
+
+
+def set_dtype(dt) -> torch.dtype:
+    """Select the 16-bit activation / weight type ("bf16" | "fp16") for subsequent ops; returns the torch dtype."""
+    global _act
+    if dt not in _DTYPES:
+        raise ValueError(f"unsupported compute dtype {dt!r}: choose 'bf16' or 'fp16'")
+    _act = _DTYPES[dt]
+    return _act
+
+
+def act_dtype() -> torch.dtype:
+    return _act
+
+
+def _dt(t: Optional[torch.Tensor] = None) -> int:
+    """UR_DT_* code of tensor `t` (or of the current compute dtype)."""
+    d = _act if t is None else t.dtype
+    if d == BF16:
+        return UR_DT_BF16
+    if d == F16:
+        return UR_DT_F16
+    raise TypeError(f"expected a bf16 / fp16 tensor, got {d}")
 
 
 def _stream():
@@ -37,96 +65,16 @@ def side_stream() -> "torch.cuda.Stream":
 
 
 def workspace(dev, nbytes=192 << 20) -> torch.Tensor:
-    """Split-K partial planes: one buffer for the side stream, one for everything else (kernels of the main branch - whatever
-    stream or capture it runs under - are ordered among themselves; the side branch runs concurrently with them)."""
+    """Split-K partial planes: one FIXED-SIZE buffer for the side stream, one for everything else (kernels of the main branch -
+    whatever stream or capture it runs under - are ordered among themselves; the side branch runs concurrently with them).
+    Allocated once per device and never regrown (captured graphs keep its address); the library falls back to fewer splits
+    when a launch would not fit."""
     cur = torch.cuda.current_stream()
     on_side = any(cur == s for s in _SIDE.values())
     key = (dev, "splitk", on_side)
-    if key not in _ws or _ws[key].numel() * 4 < nbytes:
+    if key not in _ws:
         _ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     return _ws[key]
-
-
-def _gn_ws(dev, nbytes) -> torch.Tensor:
-    key = (dev, "gn")
-    if key not in _ws or _ws[key].numel() * 8 < nbytes:
-        _ws[key] = torch.zeros(max(nbytes // 8 + 1, 1 << 17), dtype=torch.float64, device=dev)   # zero at rest
-    return _ws[key]
-
-
-def _gn_ab(dev, nbytes) -> torch.Tensor:
-    key = (dev, "gn_ab")
-    if key not in _ws or _ws[key].numel() * 4 < nbytes:
-        _ws[key] = torch.empty(max(nbytes // 4 + 1, 1 << 18), dtype=torch.float32, device=dev)
-    return _ws[key]
-
-
-class StatsArena:
-    """Bump allocator for the fp64 GroupNorm channel sums that conv epilogues produce (ur_conv_desc.gn_stats).
-    One zero-fill of the used part per forward (`reset`) replaces a zero-fill per GroupNorm."""
-
-    def __init__(self, dev, n_elems=48 << 20, dtype=torch.float64):
-        self.buf = torch.zeros(n_elems, dtype=dtype, device=dev)
-        self.off = 0
-        self.high = 0
-
-    def reset(self):
-        if self.high:
-            self.buf[:self.high].zero_()
-        self.off = 0
-        self._loop_high = 0
-
-    def mark(self):
-        return self.off
-
-    def rewind(self, mark):
-        """Reuse everything allocated since `mark` (one denoise step): re-zero that region and continue from the mark.
-        Statistics produced before the mark (encoder skip features) stay alive."""
-        hi = max(self.off, getattr(self, "_loop_high", 0))
-        self._loop_high = hi
-        if hi > mark:
-            self.buf[mark:hi].zero_()
-        self.off = mark
-
-    def alloc(self, n):
-        n = round_up(n, 2)
-        assert self.off + n <= self.buf.numel(), "GroupNorm stats arena exhausted"
-        v = self.buf[self.off:self.off + n]
-        self.off += n
-        self.high = max(self.high, self.off)
-        return v
-
-
-class _Arenas:
-    """fp64 channel-sum arena (GroupNorm) + fp32 row-sum arena (LayerNorm fusion); reset / mark / rewind act on both."""
-
-    def __init__(self, dev):
-        self.gn = StatsArena(dev)
-        self.rows = StatsArena(dev, 32 << 20, torch.float32)
-        self.off = 0          # kept for callers that poke the GroupNorm offset directly
-
-    def reset(self):
-        self.gn.reset(); self.rows.reset()
-
-    def mark(self):
-        return (self.gn.mark(), self.rows.mark())
-
-    def rewind(self, mark):
-        self.gn.rewind(mark[0])
-        self.rows.off = mark[1]          # row-sum partials are fully overwritten by their producers: no re-zeroing
-
-    def alloc(self, n):
-        return self.gn.alloc(n)
-
-
-_arena = {}
-
-
-def arena(dev=None) -> _Arenas:
-    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else dev
-    if dev not in _arena:
-        _arena[dev] = _Arenas(dev)
-    return _arena[dev]
 
 
 def ln_of(t):
@@ -135,7 +83,7 @@ def ln_of(t):
 
 
 def gn_of(t):
-    """Fused GroupNorm sums attached to tensor `t` by its producer (or None)."""
+    """(partial plane fp32 [N][P][C][2], P) attached to tensor `t` by its producer (or None): its GroupNorm statistics."""
     return getattr(t, "_gn", None)
 
 
@@ -157,7 +105,7 @@ def round_up(v, m):
 # ------------------------------------------------------------------------------------------------ weights
 @dataclass
 class PackedConv:
-    """bf16 [Cout][KH*KW*Cin] weight (K runs tap-major, channel-minor) + fp32 bias, padded for the kernel."""
+    """16-bit [Cout][KH*KW*Cin] weight (K runs tap-major, channel-minor) + fp32 bias, padded for the kernel."""
     w: torch.Tensor
     bias: Optional[torch.Tensor]
     cin: int          # padded input channels (multiple of 8)
@@ -195,7 +143,8 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=F
     cout_out = cout_p
     if pair:
         half = cout // 2
-        assert cout % 2 == 0 and half % 32 == 0, "pair activations need (Cout/2) % 32 == 0"
+        if cout % 2 or half % 32:
+            raise NotImplementedError(f"UR_E_UNSUPPORTED: pair activations (GEGLU / SimpleGate) need (Cout/2) % 32 == 0, got {half}")
         idx = torch.arange(cout, device=dev).view(2, half // 32, 32).permute(1, 0, 2).reshape(-1)   # [blk][a|g][32]
         wp = wp[idx]
         b = b[idx] if b is not None else None
@@ -205,20 +154,26 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=F
     kcm = kh == 3 and groups == 1 and cin_p % 64 == 0 and (c1 is None or c1 % 64 == 0) and os.environ.get("UR_KCM", "1") == "1"
     if kcm:
         wp = wp.reshape(cout_p, kh * kw, cin_p // 64, 64).permute(0, 2, 1, 3)
-    return PackedConv(wp.reshape(cout_p, kh * kw * cin_p).to(BF16).contiguous(),
+    return PackedConv(wp.reshape(cout_p, kh * kw * cin_p).to(_act).contiguous(),
                       None if b is None else b.contiguous(), cin_p, cout_p, cout_out, kh, groups, pair, kcm=kcm)
 
 
 # ------------------------------------------------------------------------------------------------ conv / gemm
 def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, act=UR_ACT_NONE, stride=1, pad=None,
          out_hw=None, upsample=False, out_f32=False, out_scale=1.0, out=None, yt=None, n_split=0, t_rows=0,
-         colsum=None, colsum_scale=1.0, gn=False, rows=False, ln_stats=None):
-    """x: [N,H,W,C1] bf16 (x2 optional [N,H,W,C2], virtual concat).  Returns [N,OH,OW,cout_out]."""
-    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+         gn=False, store=True, rows=False, ln_stats=None, gn_ab=None, gn_silu=False):
+    """x: [N,H,W,C1] 16-bit (x2 optional [N,H,W,C2], virtual concat).  Returns [N,OH,OW,cout_out].
+    gn=True: the consumer of the output is a GroupNorm / InstanceNorm / global average pool - leave its partial statistics
+    (out._gn); store=False (with gn): only the statistics are wanted, the output tensor is not written (returns the plane).
+    rows=True: leave per-row sums for a LayerNorm-folded consumer GEMM (out._ln).
+    gn_ab / gn_silu: read act(a*x+b) instead of x (GroupNorm apply fused into the loader; only where conv_plan says so)."""
+    if x.dtype not in (BF16, F16) or x.dtype != pc.w.dtype or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError(f"conv: x must be a contiguous 4-d {pc.w.dtype} tensor, got {x.dtype} {tuple(x.shape)}")
     n, h, w_, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[-1]
     g = pc.groups
-    assert (c1 + c2) == pc.cin * g, f"Cin mismatch: {c1}+{c2} vs {pc.cin}*{g}"
+    if (c1 + c2) != pc.cin * g:
+        raise ValueError(f"conv: Cin mismatch: {c1}+{c2} vs {pc.cin}*{g}")
     k = pc.k
     if pad is None:
         pad = (k // 2, k // 2)
@@ -227,26 +182,24 @@ def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, 
         out_hw = ((hin + 2 * pad[0] - k) // stride + 1, (win + 2 * pad[1] - k) // stride + 1)
     oh, ow = out_hw
     co_total = pc.cout_out
-    if out is None and colsum is None:
-        out = torch.empty((n, oh, ow, co_total), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    if out is None and store:
+        out = torch.empty((n, oh, ow, co_total), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     d = ConvDesc()
+    d.dtype = _dt(x)
     bias_t = pc.bias if bias is None else bias          # override: per-step (time-embedding) or per-image bias rows
     d.x, d.x2, d.w, d.bias = _ptr(x), _ptr(x2), _ptr(pc.w), _ptr(bias_t)
     if bias is not None and bias.dim() == 2 and bias.shape[0] > 1:
         d.bias_img_stride = bias.shape[1]
-    d.residual, d.y, d.yt, d.colsum = _ptr(residual), _ptr(out), _ptr(yt), _ptr(colsum)
-    stats = None
-    if gn:      # the consumer of `out` is a GroupNorm: have the epilogue (or a fallback pass) leave its channel sums
-        stats = arena(x.device).alloc(n * co_total * 2)
-        d.gn_stats = stats.data_ptr()
+    d.residual, d.y, d.yt = _ptr(residual), _ptr(out), _ptr(yt)
     if ln_stats is not None:
         assert pc.ln_colsum is not None, "weights were not packed with pack_linear_ln"
         st, parts = ln_stats
         d.ln_stats, d.ln_colsum, d.ln_eps, d.ln_dim, d.ln_parts = st.data_ptr(), pc.ln_colsum.data_ptr(), pc.ln_eps, pc.cin, parts
+    if gn_ab is not None:
+        d.gn_ab, d.gn_silu = gn_ab.data_ptr(), int(gn_silu)
     ws = workspace(x.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.N, d.H, d.W = n, h, w_
-    rstats = None
     d.C1, d.ldx, d.C2, d.ldx2 = (c1 // g if g > 1 else c1), c1, c2, c2
     d.Cout = pc.cout // g
     d.ldw = pc.w.shape[1]
@@ -259,23 +212,67 @@ def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, 
     d.k_chunk_major = int(pc.kcm and (c2 == 0 or c1 % 64 == 0))
     assert not pc.kcm or d.k_chunk_major, "chunk-major weights need a 64-aligned concat boundary"
     d.t_ld = yt.shape[-1] if yt is not None else 0
-    d.out_scale, d.colsum_scale = out_scale, colsum_scale
+    d.out_scale = out_scale
     d.nbatch = g
     if g > 1:
         d.bs_x, d.bs_w, d.bs_bias, d.bs_y = c1 // g, (pc.cout // g) * pc.w.shape[1], pc.cout // g, pc.cout_out // g
         d.bs_r = pc.cout_out // g
-    if rows:    # the consumer of `out` is a LayerNorm-fused GEMM: leave per-row (sum, sumsq) partials, one plane per N tile
-        parts = lib.ur_conv2d_row_stat_parts(d)
-        if parts <= 0:
-            check(parts if parts < 0 else -1)
-        rstats = (arena(x.device).rows.alloc(parts * n * oh * ow * 2), parts)
-        d.row_stats = rstats[0].data_ptr()
+    stats = rstats = None
+    if gn or rows:      # the consumer is a norm: plan the launch, then hand it the planes to fill (plain stores, no atomics)
+        if gn:
+            d.gn_part = 16      # dummy non-null values: the plan must see what the real launch will see
+        if rows:
+            d.row_stats = 16
+        plan = ConvPlan()
+        check(lib.ur_conv2d_plan(d, plan))
+        if gn:
+            if not store and not plan.gn_fused:
+                raise NotImplementedError("store=False needs a launch whose epilogue writes the statistics (conv_plan().gn_fused)")
+            stats = (torch.empty((n, plan.gn_parts, co_total, 2), dtype=torch.float32, device=x.device), plan.gn_parts)
+            d.gn_part = stats[0].data_ptr()
+        if rows:
+            rstats = (torch.empty((plan.row_stat_parts, n * oh * ow, 2), dtype=torch.float32, device=x.device), plan.row_stat_parts)
+            d.row_stats = rstats[0].data_ptr()
     check(lib.ur_conv2d_nhwc(d, _stream()))
+    if not store:
+        return stats
     if stats is not None:
         out._gn = stats
     if rstats is not None:
         out._ln = rstats
     return out
+
+
+def conv_plan(x: torch.Tensor, pc: PackedConv, *, x2=None, stride=1, pad=None, upsample=False, gn=False, gn_ab=False,
+              act=UR_ACT_NONE, residual=False, store=True) -> ConvPlan:
+    """What `conv` would do for this (shape, weights) - used to decide whether the GroupNorm apply can ride in the conv."""
+    n, h, w_, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    k, g = pc.k, pc.groups
+    pad = (k // 2, k // 2) if pad is None else pad
+    hin, win = (h * 2, w_ * 2) if upsample else (h, w_)
+    oh, ow = (hin + 2 * pad[0] - k) // stride + 1, (win + 2 * pad[1] - k) // stride + 1
+    d = ConvDesc()
+    d.dtype = _dt(x)
+    d.x, d.w, d.y = 16, 16, (16 if store else None)
+    d.x2 = 16 if c2 else None
+    d.residual = 16 if residual else None
+    d.gn_part = 16 if gn else None
+    d.gn_ab = 16 if gn_ab else None
+    ws = workspace(x.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    d.N, d.H, d.W = n, h, w_
+    d.C1, d.ldx, d.C2, d.ldx2 = (c1 // g if g > 1 else c1), c1, c2, c2
+    d.Cout, d.ldw, d.ldy, d.ldr = pc.cout // g, pc.w.shape[1], pc.cout_out, pc.cout_out if residual else 0
+    d.KH = d.KW = k
+    d.stride, d.pad_t, d.pad_l, d.OH, d.OW = stride, pad[0], pad[1], oh, ow
+    d.upsample2x, d.act, d.out_scale, d.nbatch = int(upsample), act, 1.0, g
+    d.k_chunk_major = int(pc.kcm and (c2 == 0 or c1 % 64 == 0))
+    if g > 1:
+        d.bs_x, d.bs_w, d.bs_bias, d.bs_y, d.bs_r = c1 // g, (pc.cout // g) * pc.w.shape[1], pc.cout // g, pc.cout_out // g, pc.cout_out // g
+    plan = ConvPlan()
+    check(lib.ur_conv2d_plan(d, plan))
+    return plan
 
 
 def pack_linear_ln(weight, bias, gamma, beta, eps, dev, *, pair=False) -> PackedConv:
@@ -286,7 +283,7 @@ def pack_linear_ln(weight, bias, gamma, beta, eps, dev, *, pair=False) -> Packed
     wf = w * g[None, :]
     t = w @ b0 + (bias.detach().to(dev, torch.float32) if bias is not None else 0.0)
     pc = pack_conv(wf, t, dev, pair=pair)
-    pc.ln_colsum = pc.w.float().sum(dim=1).contiguous()          # in packed (possibly a|g interleaved) row order
+    pc.ln_colsum = pc.w.float().sum(dim=1).contiguous()          # of the ROUNDED weights, in packed (possibly a|g interleaved) row order
     pc.ln_eps = float(eps)
     return pc
 
@@ -315,8 +312,9 @@ def bmm_nt(a: torch.Tensor, bmat: torch.Tensor, *, out_f32=False, out_scale=1.0)
     B, M, K = a.shape
     N = bmat.shape[1]
     assert a.stride(2) == 1 and bmat.stride(2) == 1 and K % 8 == 0 and N % 4 == 0
-    out = torch.empty((B, M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    out = torch.empty((B, M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
     d = ConvDesc()
+    d.dtype = _dt(a)
     d.x, d.w, d.y = a.data_ptr(), bmat.data_ptr(), out.data_ptr()
     ws = workspace(a.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -329,37 +327,76 @@ def bmm_nt(a: torch.Tensor, bmat: torch.Tensor, *, out_f32=False, out_scale=1.0)
 
 
 # ------------------------------------------------------------------------------------------------ norms
-def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu=False, x2=None, use_pre=True):
-    """x: [N,H,W,C1] bf16 (+ optional x2 [N,H,W,C2], normalised as one concatenated tensor) -> [N,H,W,C1+C2].
-    gamma/beta fp32 [C] or None (InstanceNorm when groups == C)."""
-    assert x.dtype == BF16 and x.is_contiguous()
+def gn_partials(x: torch.Tensor):
+    """(plane, P) of x: the producer's, or from a statistics pass over x (deterministic partial planes, no atomics)."""
+    pre = gn_of(x)
+    if pre is not None:
+        return pre
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    parts = lib.ur_groupnorm_stats_parts(n, hw, c)
+    if parts <= 0:
+        check(parts if parts < 0 else -1)
+    plane = torch.empty((n, parts, c, 2), dtype=torch.float32, device=x.device)
+    check(lib.ur_groupnorm_stats(x.data_ptr(), plane.data_ptr(), n, hw, c, _dt(x), _stream()))
+    return plane, parts
+
+
+def gn_finalize(x: torch.Tensor, gamma, beta, groups: int, eps: float, x2=None, use_pre=True, want_mean=False):
+    """GroupNorm statistics of x (| x2, virtually concatenated) -> fp32 ab [N][2][C] with GroupNorm(x) = a*x + b
+    (want_mean: the [N][groups] group means instead)."""
     n, c1 = x.shape[0], x.shape[-1]
     c2 = 0 if x2 is None else x2.shape[-1]
     hw = x.numel() // (n * c1)
-    out = torch.empty((*x.shape[:-1], c1 + c2), dtype=BF16, device=x.device)
-    ws = _gn_ws(x.device, lib.ur_groupnorm_ws_bytes(n, c1 + c2))
-    ab = _gn_ab(x.device, lib.ur_groupnorm_ab_bytes(n, c1 + c2))
-    pre1 = gn_of(x) if use_pre else None
-    pre2 = gn_of(x2) if (use_pre and x2 is not None) else None
-    check(lib.ur_groupnorm_nhwc(x.data_ptr(), _ptr(x2), out.data_ptr(), _ptr(gamma), _ptr(beta), n, hw, c1, c2, groups, eps,
-                                int(silu), ws.data_ptr(), ab.data_ptr(), _ptr(pre1), _ptr(pre2), _stream()))
+    if not use_pre:
+        x = x.view(x.shape)          # fresh tensor object: no producer attributes
+        x2 = None if x2 is None else x2.view(x2.shape)
+    p1, n1 = gn_partials(x)
+    p2, n2 = gn_partials(x2) if x2 is not None else (None, 0)
+    out = torch.empty((n, groups) if want_mean else (n, 2, c1 + c2), dtype=torch.float32, device=x.device)
+    check(lib.ur_groupnorm_finalize(p1.data_ptr(), n1, c1, _ptr(p2), n2, c2, _ptr(gamma), _ptr(beta), n, hw, groups, eps,
+                                    None if want_mean else out.data_ptr(), out.data_ptr() if want_mean else None, _stream()))
     return out
 
 
+def gn_finalize_planes(plane: torch.Tensor, parts: int, hw: int):
+    """Channel means [N][C] straight from a partial plane [N][P][C][2] (statistics-only conv launch)."""
+    n, c = plane.shape[0], plane.shape[2]
+    out = torch.empty((n, c), dtype=torch.float32, device=plane.device)
+    check(lib.ur_groupnorm_finalize(plane.data_ptr(), parts, c, None, 0, 0, None, None, n, hw, c, 0.0, None, out.data_ptr(), _stream()))
+    return out
+
+
+def gn_apply(x: torch.Tensor, ab: torch.Tensor, silu=False, x2=None):
+    n, c1 = x.shape[0], x.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    hw = x.numel() // (n * c1)
+    out = torch.empty((*x.shape[:-1], c1 + c2), dtype=x.dtype, device=x.device)
+    check(lib.ur_groupnorm_apply_act(x.data_ptr(), _ptr(x2), out.data_ptr(), ab.data_ptr(), n, hw, c1, c2, int(silu), _dt(x), _stream()))
+    return out
+
+
+def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu=False, x2=None, use_pre=True):
+    """x: [N,H,W,C1] 16-bit (+ optional x2 [N,H,W,C2], normalised as one concatenated tensor) -> [N,H,W,C1+C2].
+    gamma/beta fp32 [C] or None (InstanceNorm when groups == C)."""
+    assert x.dtype in (BF16, F16) and x.is_contiguous()
+    return gn_apply(x, gn_finalize(x, gamma, beta, groups, eps, x2=x2, use_pre=use_pre), silu, x2=x2)
+
+
 def layer_norm(x: torch.Tensor, gamma, beta, eps: float):
-    assert x.dtype == BF16 and x.is_contiguous()
+    assert x.dtype in (BF16, F16) and x.is_contiguous()
     c = x.shape[-1]
     out = torch.empty_like(x)
-    check(lib.ur_layernorm_rows(x.data_ptr(), out.data_ptr(), _ptr(gamma), _ptr(beta), x.numel() // c, c, eps, _stream()))
+    check(lib.ur_layernorm_rows(x.data_ptr(), out.data_ptr(), _ptr(gamma), _ptr(beta), x.numel() // c, c, eps, _dt(x), _stream()))
     return out
 
 
 def softmax_rows(s: torch.Tensor, ldp=None):
-    """s: [..., cols] fp32 -> bf16 probabilities [..., ldp] (columns >= cols are zero)."""
+    """s: [..., cols] fp32 -> 16-bit probabilities [..., ldp] (columns >= cols are zero)."""
     cols = s.shape[-1]
     ldp = ldp or round_up(cols, 8)
-    p = torch.empty((*s.shape[:-1], ldp), dtype=BF16, device=s.device)
-    check(lib.ur_softmax_rows_f32(s.data_ptr(), p.data_ptr(), s.numel() // cols, cols, ldp, _stream()))
+    p = torch.empty((*s.shape[:-1], ldp), dtype=_act, device=s.device)
+    check(lib.ur_softmax_rows_f32(s.data_ptr(), p.data_ptr(), s.numel() // cols, cols, ldp, _dt(), _stream()))
     return p
 
 
@@ -368,31 +405,29 @@ def attention(q, k, vt, heads: int, head_dim: int, tq: int, tk: int, scale: floa
               batch: int, out=None):
     """q:[B,Tq,ldq] k:[B?,Tk,ldk] vt:[B?,H*D,ldvt] (raw tensors; strides given explicitly) -> o [B,Tq,H*D]."""
     c = heads * head_dim
-    out = torch.empty((batch, tq, c), dtype=BF16, device=q.device) if out is None else out
+    out = torch.empty((batch, tq, c), dtype=q.dtype, device=q.device) if out is None else out
     check(lib.ur_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, tq, tk, head_dim,
-                               ldq, ldk, vt.shape[-1], c, bs_q, bs_k, bs_vt, tq * c, scale, _stream()))
+                               ldq, ldk, vt.shape[-1], c, bs_q, bs_k, bs_vt, tq * c, scale, _dt(q), _stream()))
     return out
 
 
 # ------------------------------------------------------------------------------------------------ misc
 def dwconv3x3(x, w9c, bias, gate=False):
     n, h, w_, c = x.shape
-    out = torch.empty((n, h, w_, c // 2 if gate else c), dtype=BF16, device=x.device)
-    check(lib.ur_dwconv3x3_nhwc(x.data_ptr(), w9c.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w_, c, int(gate), _stream()))
+    out = torch.empty((n, h, w_, c // 2 if gate else c), dtype=x.dtype, device=x.device)
+    check(lib.ur_dwconv3x3_nhwc(x.data_ptr(), w9c.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w_, c, int(gate), _dt(x), _stream()))
     return out
 
 
 def avgpool(x):
-    n, c = x.shape[0], x.shape[-1]
-    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    check(lib.ur_avgpool_hw(x.data_ptr(), out.data_ptr(), n, x.numel() // (n * c), c, _stream()))
-    return out
+    """Mean over HW -> fp32 [N][C]: a finalize over the tensor's (producer-side or freshly computed) partial sums."""
+    return gn_finalize(x, None, None, x.shape[-1], 0.0, want_mean=True)
 
 
 def scale_channels(x, s, residual=None):
     n, c = x.shape[0], x.shape[-1]
     out = torch.empty_like(x)
-    check(lib.ur_scale_channels(x.data_ptr(), s.data_ptr(), _ptr(residual), out.data_ptr(), n, x.numel() // (n * c), c, _stream()))
+    check(lib.ur_scale_channels(x.data_ptr(), s.data_ptr(), _ptr(residual), out.data_ptr(), n, x.numel() // (n * c), c, _dt(x), _stream()))
     return out
 
 
@@ -400,14 +435,14 @@ def spade_modulate(n, gb, residual=None):
     """y = n * (1 + gamma) + beta (+ residual); gb [..., 2C] = gamma | beta (spade.py:69)."""
     c = n.shape[-1]
     out = torch.empty_like(n)
-    check(lib.ur_spade_modulate(n.data_ptr(), gb.data_ptr(), gb.shape[-1], _ptr(residual), out.data_ptr(), n.numel() // c, c, _stream()))
+    check(lib.ur_spade_modulate(n.data_ptr(), gb.data_ptr(), gb.shape[-1], _ptr(residual), out.data_ptr(), n.numel() // c, c, _dt(n), _stream()))
     return out
 
 
 def axpy_channels(a, b, s):
     c = a.shape[-1]
     out = torch.empty_like(a)
-    check(lib.ur_axpy_channels(a.data_ptr(), b.data_ptr(), s.data_ptr(), out.data_ptr(), a.numel() // c, c, _stream()))
+    check(lib.ur_axpy_channels(a.data_ptr(), b.data_ptr(), s.data_ptr(), out.data_ptr(), a.numel() // c, c, _dt(a), _stream()))
     return out
 
 
@@ -434,13 +469,13 @@ def vec_mul_group(a, b, groups):
 
 
 def nchw_to_nhwc(x: torch.Tensor, cpad=None, image=False):
-    """fp32 NCHW -> bf16 NHWC (channels zero-padded to a multiple of 8); image=True applies x*2-1."""
+    """fp32 NCHW -> 16-bit NHWC (channels zero-padded to a multiple of 8); image=True applies x*2-1."""
     x = x.contiguous().float()
     n, c, h, w_ = x.shape
     cpad = cpad or round_up(c, 8)
-    out = torch.empty((n, h, w_, cpad), dtype=BF16, device=x.device)
+    out = torch.empty((n, h, w_, cpad), dtype=_act, device=x.device)
     fn = lib.ur_image_to_nhwc if image else lib.ur_nchw_f32_to_nhwc
-    check(fn(x.data_ptr(), out.data_ptr(), n, c, h, w_, cpad, _stream()))
+    check(fn(x.data_ptr(), out.data_ptr(), n, c, h, w_, cpad, _dt(), _stream()))
     return out
 
 
@@ -449,8 +484,8 @@ def image_resize_pad(img: torch.Tensor, rh: int, rw: int, ph: int, pw: int, mul=
     img = img.contiguous().float()
     n, c, h, w_ = img.shape
     cpad = cpad or round_up(c, 8)
-    out = torch.empty((n, rh + ph, rw + pw, cpad), dtype=BF16, device=img.device)
-    check(lib.ur_image_resize_pad_nhwc(img.data_ptr(), out.data_ptr(), n, c, h, w_, rh, rw, ph, pw, cpad, mul, add, _stream()))
+    out = torch.empty((n, rh + ph, rw + pw, cpad), dtype=_act, device=img.device)
+    check(lib.ur_image_resize_pad_nhwc(img.data_ptr(), out.data_ptr(), n, c, h, w_, rh, rw, ph, pw, cpad, mul, add, _dt(), _stream()))
     return out
 
 
@@ -459,7 +494,7 @@ def image_unpad_resize(x: torch.Tensor, c: int, crop_hw, out_hw, mul=1.0, add=0.
     n, xh, xw, ld = x.shape
     out = torch.empty((n, c, out_hw[0], out_hw[1]), dtype=torch.float32, device=x.device)
     check(lib.ur_image_unpad_resize_nchw(x.data_ptr(), int(x.dtype == torch.float32), out.data_ptr(), n, c, xh, xw, ld, crop_hw[0],
-                                         crop_hw[1], out_hw[0], out_hw[1], mul, add, int(quantize), _stream()))
+                                         crop_hw[1], out_hw[0], out_hw[1], mul, add, int(quantize), _dt() if x.dtype == torch.float32 else _dt(x), _stream()))
     return out
 
 
@@ -467,36 +502,37 @@ def nhwc_to_nchw(x: torch.Tensor, c=None, mul=1.0, add=0.0):
     n, h, w_, ld = x.shape
     c = c or ld
     out = torch.empty((n, c, h, w_), dtype=torch.float32, device=x.device)
-    check(lib.ur_nhwc_to_nchw_f32(x.data_ptr(), int(x.dtype == torch.float32), out.data_ptr(), n, c, h, w_, ld, mul, add, _stream()))
+    check(lib.ur_nhwc_to_nchw_f32(x.data_ptr(), int(x.dtype == torch.float32), out.data_ptr(), n, c, h, w_, ld, mul, add,
+                                  _dt() if x.dtype == torch.float32 else _dt(x), _stream()))
     return out
 
 
 def vae_sample(moments_f32, noise_nchw, clat, scale):
     n, h, w_, ld = moments_f32.shape
     z = torch.empty((n, h, w_, 8), dtype=torch.float32, device=moments_f32.device)
-    zb = torch.empty((n, h, w_, 8), dtype=BF16, device=moments_f32.device)
+    zb = torch.empty((n, h, w_, 8), dtype=_act, device=moments_f32.device)
     check(lib.ur_vae_sample(moments_f32.data_ptr(), ld, noise_nchw.data_ptr(), z.data_ptr(), zb.data_ptr(), n, h * w_, clat, 8,
-                            scale, _stream()))
+                            scale, _dt(), _stream()))
     return z, zb
 
 
 def add_noise(z0, noise_nchw, clat, sa, sb):
     n, h, w_, cp = z0.shape
-    zt, zb = torch.empty_like(z0), torch.empty(z0.shape, dtype=BF16, device=z0.device)
-    check(lib.ur_add_noise(z0.data_ptr(), noise_nchw.data_ptr(), zt.data_ptr(), zb.data_ptr(), n, h * w_, clat, cp, sa, sb, _stream()))
+    zt, zb = torch.empty_like(z0), torch.empty(z0.shape, dtype=_act, device=z0.device)
+    check(lib.ur_add_noise(z0.data_ptr(), noise_nchw.data_ptr(), zt.data_ptr(), zb.data_ptr(), n, h * w_, clat, cp, sa, sb, _dt(), _stream()))
     return zt, zb
 
 
 def ddim_step_(zt, zt_bf16, eps_f32, clat, c_x, c_e):
     cp = zt.shape[-1]
     check(lib.ur_ddim_step(zt.data_ptr(), eps_f32.data_ptr(), eps_f32.shape[-1], zt_bf16.data_ptr(), zt.numel() // cp, clat, cp,
-                           c_x, c_e, _stream()))
+                           c_x, c_e, _dt(zt_bf16), _stream()))
 
 
 def f32_to_bf16(x, c, mul=1.0, cpad=8):
     ld = x.shape[-1]
-    out = torch.empty((*x.shape[:-1], cpad), dtype=BF16, device=x.device)
-    check(lib.ur_f32_to_bf16_scaled(x.data_ptr(), ld, out.data_ptr(), x.numel() // ld, c, cpad, mul, _stream()))
+    out = torch.empty((*x.shape[:-1], cpad), dtype=_act, device=x.device)
+    check(lib.ur_f32_to_bf16_scaled(x.data_ptr(), ld, out.data_ptr(), x.numel() // ld, c, cpad, mul, _dt(), _stream()))
     return out
 
 

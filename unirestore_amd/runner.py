@@ -40,6 +40,60 @@ def validation_step(model, lq: torch.Tensor, hq: torch.Tensor = None, task: str 
 
 
 def psnr(pred: torch.Tensor, target: torch.Tensor, data_range: float = 1.0) -> float:
-    """Full-reference PSNR over the batch (what `val_lq/psnr` reports, eval_image_restoration.py:102-104)."""
+    """Full-reference PSNR over the batch (what `val_lq/psnr` reports, eval_image_restoration.py:102-104,181)."""
     mse = torch.mean((pred.double().cpu() - target.double().cpu()) ** 2)
     return float(10.0 * torch.log10(data_range ** 2 / mse))
+
+
+def ssim(pred: torch.Tensor, target: torch.Tensor, data_range: float = 1.0, win: int = 7) -> float:
+    """Mean structural similarity, scikit-image's defaults (`structural_similarity`: uniform 7x7 window, K1 0.01, K2 0.03,
+    sample covariance, borders of (win-1)//2 pixels dropped), averaged over channels and the batch - what the reference's
+    `SKSSIM(data_range=1.0)` metric reports (eval_image_restoration.py:182)."""
+    import torch.nn.functional as F
+    x, y = pred.double().cpu(), target.double().cpu()
+    c = x.shape[1]
+    k = torch.full((c, 1, win, win), 1.0 / (win * win), dtype=torch.float64)
+    filt = lambda t: F.conv2d(t, k, groups=c)                     # 'valid' = the cropped interior skimage averages over
+    npx = win * win
+    cov_norm = npx / (npx - 1.0)
+    ux, uy = filt(x), filt(y)
+    vx = cov_norm * (filt(x * x) - ux * ux)
+    vy = cov_norm * (filt(y * y) - uy * uy)
+    vxy = cov_norm * (filt(x * y) - ux * uy)
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+    return float(s.mean())
+
+
+class LitUniFIE:
+    """The caller the reference builds around the path (`LitUniFIE{IR,MTL}`, src/core/engine_unifie.py:29-42,227-236 +
+    ImageRestorationEvaluator.validation_step) without Lightning: owns a `DiffUIE`, maps `forward` over the input list and
+    runs the evaluator's crop / restore / quantise / metric steps on a batch tuple `(lq, hq, gt, fname, task)`."""
+
+    def __init__(self, model_kwargs: dict, save_image: bool = False, eval_mode: str = "FR", need_crop: bool = True,
+                 dtype: str = "bf16", hf_root: str = None, model=None, **_ignored):
+        from . import checkpoint
+        self.model_kwargs, self.need_crop, self.eval_mode = model_kwargs, need_crop, eval_mode
+        tedit = model_kwargs.get("tedit") or {}
+        self.task_dict = tedit.get("task", [])
+        self.model = model if model is not None else checkpoint.build_from_config(model_kwargs, hf_root=hf_root, dtype=dtype)
+        self.totals = dict(psnr=0.0, ssim=0.0, images=0)
+
+    def forward(self, inputs: Sequence[torch.Tensor], task: str, quantize: bool = False) -> List[torch.Tensor]:
+        return forward(self.model, inputs, task, quantize=quantize)
+
+    def validation_step(self, batch, eval_types: Sequence[str] = ("lq",)):
+        lq, hq, _gt, _fname, task = batch
+        preds, hq_c = validation_step(self.model, lq, hq, task=task if task in self.task_dict else "ir",
+                                      need_crop=self.need_crop, eval_types=eval_types)
+        if hq_c is not None and self.eval_mode in ("FR", "ALL") and preds[-1].shape == (crop_tensor(hq) if self.need_crop else hq).shape:
+            tgt = crop_tensor(hq) if self.need_crop else hq
+            n = preds[-1].shape[0]
+            self.totals["psnr"] += psnr(preds[-1], tgt) * n
+            self.totals["ssim"] += ssim(preds[-1], tgt) * n
+            self.totals["images"] += n
+        return preds
+
+    def metrics(self) -> dict:
+        n = max(self.totals["images"], 1)
+        return {"val_lq/psnr": self.totals["psnr"] / n, "val_lq/ssim": self.totals["ssim"] / n, "images": self.totals["images"]}
