@@ -78,19 +78,19 @@ def cpu_baseline(model, denoise_steps):
         t3 = time.perf_counter()
     t_once, t_step = (t1 - t0) + (t3 - t2), (t2 - t1)
     total = t_once + denoise_steps * t_step
-    # parity of the HIP path on the same sample (1-step schedule -> same graph as the oracle run above)
-    import unirestore_amd.modules as M
-    m1 = model
-    saved = (m1.num_inference_steps, m1.timesteps)
-    m1.num_inference_steps, m1.timesteps = 1, osched.ddim_timesteps(1)
-    m1._tables_ready = False
-    m1._graphs.clear()
-    py, pz0, pzt = m1(img, "ir", noise=noise, return_latents=True)
+    # parity of the HIP path on the same sample (1-step schedule -> same graph as the oracle run above), per 16-bit type
+    saved_steps, saved_dtype = model.num_inference_steps, model.dtype
+    model.set_num_inference_steps(1)
     rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())
-    parity = dict(z0_rel_l2=rel(pz0, z0), zt_rel_l2=rel(pzt, zt1), image_rel_l2=rel(py, out), sample="B=1 512x512, 1 DDIM step")
-    m1.num_inference_steps, m1.timesteps = saved
-    m1._tables_ready = False
-    m1._graphs.clear()
+    parity = dict(sample="B=1 512x512, 1 DDIM step, same weights / image / noise as the oracle run",
+                  tolerance="bf16: <= 1.5x the emulated 16-bit-operand + stored-activation budget (oracle/emulate.py: z0 5.8e-3, zt 4.6e-3, "
+                            "image 4.7e-3); fp16: <= 1e-3 (north star)")
+    for dt in ("bf16", "fp16"):
+        model.set_dtype(dt)
+        py, pz0, pzt = model(img, "ir", noise=noise, return_latents=True)
+        parity[dt] = dict(z0_rel_l2=rel(pz0, z0), zt_rel_l2=rel(pzt, zt1), image_rel_l2=rel(py, out))
+    model.set_dtype(saved_dtype)
+    model.set_num_inference_steps(saved_steps)
     return dict(value=1.0 / total, unit="images/s", cores=cores, kind="port",
                 sample=f"1 image 512x512: once-part {t_once:.2f}s + 1 denoise step {t_step:.2f}s, extrapolated to "
                        f"{denoise_steps} steps ({total:.1f}s/image)"), parity
@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--denoise-steps", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit storage / MFMA operand type (headline: bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -118,7 +119,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    model = build_model(args.denoise_steps, dev, rank, world)
+    model = build_model(args.denoise_steps, dev, rank, world, args.dtype)
     from unirestore_amd import ops
 
     B, R = args.batch, args.res
@@ -158,8 +159,8 @@ def main():
         result = {
             "metric": "restored 512x512 images/sec @ 20 denoise steps (whole job)", "value": world * B * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"PIR {R}x{R} batch={B}/GPU, {args.denoise_steps} DDIM steps, bf16, hipGraph replay "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"PIR {R}x{R} batch={B}/GPU, {args.denoise_steps} DDIM steps, {args.dtype}, hipGraph replay "
                                    "(BASELINE.json configs[1]; configs[2] shape for N=8)",
                        "global_batch": world * B, "per_gpu_batch": B, "image": R, "denoise_steps": args.denoise_steps,
                        "parallelism": f"image-parallel dp{world}", "weights": "seeded random init (no checkpoints reachable)"},
@@ -176,26 +177,42 @@ def main():
         rep = ops.profile_report()
         ops.profile_enable(False)
         model.use_graph = True
+        # every family against the roof that bounds it: contractions (conv / GEMM / attention) vs the dense 16-bit MFMA peak,
+        # everything else (norm passes, stencils, layout kernels) vs HBM
+        MFMA_FAMS = ("conv3x3_igemm", "gemm1x1_igemm", "attention")
         fam = {}
         for k, v in rep.items():
             sec = v["ms"] / 1e3
+            tf = v["flops"] / sec / 1e12 if v["flops"] else None
+            gb = v["bytes"] / sec / 1e9 if v["bytes"] else None
+            mf = k in MFMA_FAMS
             fam[k] = {"launches": v["launches"], "ms": round(v["ms"], 3), "avg_us": round(v["ms"] * 1e3 / max(v["launches"], 1), 2),
-                      "tflops": round(v["flops"] / sec / 1e12, 1) if v["flops"] else None,
-                      "gbs": round(v["bytes"] / sec / 1e9, 1) if v["bytes"] else None}
-        dom = rep["conv3x3_igemm"]
-        ach = dom["flops"] / (dom["ms"] / 1e3) / 1e12
-        result["roofline"] = {"kernel": "conv3x3 implicit GEMM (igemm_halo_kernel + igemm fallbacks), all launches of one forward",
-                              "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": dom["launches"],
-                              "avg_launch_us": fam["conv3x3_igemm"]["avg_us"],
-                              "flops_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2), "flops_unit": "GFLOP"}
-        # HBM bytes of the most frequent launch of the family (conv3x3 320->320 @64x64, B=8: 140 launches per forward),
-        # from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE), committed file.
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_halo_conv.json")
-        if os.path.exists(pmc):
-            pj = json.load(open(pmc))
-            result["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_note"] = pj["note"]
+                      "tflops": round(tf, 1) if tf else None, "gbs": round(gb, 1) if gb else None, "bound": "mfma" if mf else "hbm",
+                      "frac": round((tf / MFMA_PEAK_TFLOPS) if mf else ((gb or 0.0) / HBM_PEAK_GBS), 4)}
+        dom_name = max(rep, key=lambda k: rep[k]["ms"])                      # the family the forward spends most time in
+        dom, mf = rep[dom_name], dom_name in MFMA_FAMS
+        sec = dom["ms"] / 1e3
+        ach = (dom["flops"] / sec / 1e12) if mf else (dom["bytes"] / sec / 1e9)
+        peak = MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBS
+        names = {"conv3x3_igemm": "conv3x3 implicit GEMM (igemm_halo_kernel / igemm_halo_img_kernel + fallbacks)",
+                 "gemm1x1_igemm": "1x1 conv / Linear GEMMs (gemm_glds_kernel / igemm_kernel)", "attention": "flash attention (attn_fwd_kernel)"}
+        result["roofline"] = {"kernel": names.get(dom_name, dom_name) + ", all launches of one forward (the family with the most time)",
+                              "family": dom_name, "bound": "mfma" if mf else "hbm", "achieved": round(ach, 1), "peak": peak,
+                              "unit": "TFLOP/s" if mf else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
+                              "launches": dom["launches"], "avg_launch_us": fam[dom_name]["avg_us"],
+                              "work_per_launch": round((dom["flops"] if mf else dom["bytes"]) / dom["launches"] / 1e9, 3),
+                              "work_unit": "GFLOP" if mf else "GB",
+                              "share_of_forward": round(dom["ms"] / sum(v["ms"] for v in rep.values()), 3)}
+        # HBM bytes of the most frequent launch of the conv family (conv3x3 320->320 @64x64, B=8), from separate rocprofv3 --pmc
+        # passes (FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE), committed file; null for other families
+        for cand in ("r2_pmc_dominant.json", "r1_pmc_halo_conv.json"):
+            pmc = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                if pj.get("family", "conv3x3_igemm") == dom_name:
+                    result["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
+                    result["roofline"]["traffic_note"] = pj["note"]
+                break
         result["families"] = fam
         result["profiled_forward_ms"] = round(sum(v["ms"] for v in rep.values()), 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

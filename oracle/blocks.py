@@ -86,6 +86,10 @@ def _sdpa(q, k, v, heads):
     q = q.view(b, tq, heads, d).transpose(1, 2)
     k = k.view(b, -1, heads, d).transpose(1, 2)
     v = v.view(b, -1, heads, d).transpose(1, 2)
+    if tq * k.shape[2] > (1 << 22):
+        # long sequences (>= 2048 x 2048; 16384 tokens at 1024x1024): same mathematics through PyTorch's fused fp32 kernel, which
+        # does not materialise the [heads, Tq, Tk] score tensor (5 GB per attention at 16384 tokens) - minutes -> seconds on CPU
+        return F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, tq, c)
     w = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(d), dim=-1)
     return (w @ v).transpose(1, 2).reshape(b, tq, c)
 

@@ -70,8 +70,10 @@ def _pair(M, seed=0, steps=2, dtype="bf16", kw=None):
 
 
 # measured on MI355X (rel-L2 vs the fp32 oracle, tiny configuration): tolerance = 1.5 x measured, per compute dtype
-TOL = {"bf16": dict(ctrl=9e-3, eps=9e-3, z=6e-3, res=8e-3, img=8e-3, fwd_z0=9e-3, fwd_zt=7e-3, fwd_img=6e-3),
-       "fp16": dict(ctrl=1.2e-3, eps=1.2e-3, z=9e-4, res=1.2e-3, img=1.2e-3, fwd_z0=1.2e-3, fwd_zt=1e-3, fwd_img=1e-3)}
+TOL = {"bf16": dict(ctrl=2.9e-2, eps=1.3e-2, z=7e-3, res=2.4e-2, img=1.4e-2, fwd_z0=8.5e-3, fwd_zt=6e-3, fwd_img=5.5e-3),
+       "fp16": dict(ctrl=3e-3, eps=1.7e-3, z=9.5e-4, res=3e-3, img=1.75e-3, fwd_z0=1.05e-3, fwd_zt=7.6e-4, fwd_img=7e-4)}
+# measured (r2, MI355X): bf16 ctrl 0.74-1.9e-2 (3x2-pixel maps), eps 8.7e-3, z 4.7e-3, res 1.56e-2, img 9.2e-3, forward
+# 5.6e-3 / 4.0e-3 / 3.7e-3; fp16 ctrl 0.9-2.0e-3, eps 1.1e-3, z 6.3e-4, res 2.0e-3, img 1.15e-3, forward 7.0e-4 / 5.0e-4 / 4.6e-4
 DTYPES = ["bf16", "fp16"]
 
 

@@ -405,3 +405,36 @@ def test_conv1x1_virtual_concat_shortcuts(ops, n, hw, c1, c2, cout):
     b = torch.randn(cout, generator=g)
     y = ops.conv(_nhwc(x[:, :c1]), ops.pack_conv(wt, b, "cuda"), x2=_nhwc(x[:, c1:]))
     assert rel_l2(_nchw(y), F.conv2d(x, wt, b)) < TOL_BF16
+
+
+@pytest.mark.parametrize("n,c1,c2,cout,h,w,ups", [(8, 128, 0, 256, 32, 64, False),       # 8x32 halo patches, 128 tiles
+                                                  (4, 320, 320, 320, 32, 64, False),     # virtual concat, 160-wide tiles
+                                                  (8, 64, 0, 160, 16, 32, True),         # fused nearest-2x upsample
+                                                  (8, 256, 0, 128, 32, 64, False),       # 64 tiles -> channel-chunk split + reduce pass
+                                                  (8, 128, 64, 160, 24, 96, False),      # concat boundary inside the K range
+                                                  (3, 256, 0, 128, 16, 16, False), (2, 640, 640, 256, 16, 16, False)])   # 16x16 whole-image tiles
+def test_conv_groupnorm_prologue(ops, n, c1, c2, cout, h, w, ups):
+    """GroupNorm apply + SiLU fused into the 3x3 conv's loader (ur_conv_desc.gn_ab: halo 8x32 patches and 16x16 whole-image
+    tiles, virtual concat, fused upsample, chunk-split K): equal to applying the GroupNorm first, and to PyTorch."""
+    g = _gen(c1 + c2 + cout + h)
+    cin = c1 + c2
+    x = _rb(torch.randn(n, cin, h, w, generator=g) * 1.5 + 0.3)
+    wt = _rb(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)); b = torch.randn(cout, generator=g)
+    ga, be = torch.randn(cin, generator=g), torch.randn(cin, generator=g)
+    xa, xb = _nhwc(x[:, :c1]), (_nhwc(x[:, c1:]) if c2 else None)
+    pc = ops.pack_conv(wt, b, "cuda", c1=c1 if c2 else None)
+    plan = ops.conv_plan(xa, pc, x2=xb, upsample=ups, gn=True, gn_ab=True)
+    assert plan.prologue_ok, "shape should take a halo kernel"
+    ab = ops.gn_finalize(xa, ga.cuda(), be.cuda(), 32, 1e-5, x2=xb)
+    fused = ops.conv(xa, pc, x2=xb, upsample=ups, gn_ab=ab, gn_silu=True, gn=True)
+    two_pass = ops.conv(ops.gn_apply(xa, ab, silu=True, x2=xb), pc, upsample=ups, gn=True)
+    assert torch.equal(fused, two_pass)                               # same rounded operands, same summation order
+    assert torch.equal(ops.gn_of(fused)[0], ops.gn_of(two_pass)[0])
+    hn = F.silu(F.group_norm(x, 32, ga, be, eps=1e-5))
+    ref = F.conv2d(F.interpolate(hn, scale_factor=2.0, mode="nearest") if ups else hn, wt, b, padding=1)
+    assert rel_l2(_nchw(fused), ref) < 2 * TOL_BF16                   # the normalised operand is rounded to 16 bits once more
+    nosilu = ops.conv(xa, pc, x2=xb, upsample=ups, gn_ab=ab, gn_silu=False)
+    assert torch.equal(nosilu, ops.conv(ops.gn_apply(xa, ab, silu=False, x2=xb), pc, upsample=ups))
+    if not ops.conv_plan(_nhwc(x[:, :8, :5, :7]), ops.pack_conv(wt[:, :8], b, "cuda"), gn_ab=True).prologue_ok:
+        with pytest.raises(NotImplementedError):                      # UR_E_UNSUPPORTED where the launch cannot honour gn_ab
+            ops.conv(_nhwc(x[:, :8, :5, :7]), ops.pack_conv(wt[:, :8], b, "cuda"), gn_ab=ab, gn_silu=True)

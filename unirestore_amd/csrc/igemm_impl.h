@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
       const bool ab_now = gnp && tap == 0 && next_chunk;    // (+1 DMA op in this iteration, counted in the wait below)
       if (ab_now) issue_ab(c + 1);
       // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it under this tap's MFMAs
-      if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, tap >= 2 ? tap - 2 : 0);
+      if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
@@ -1438,6 +1438,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const hbuf = smem;
   unsigned char* const wring = smem + 2 * HBYTES;
+  unsigned char* const abuf = wring + 3 * WBYTES;        // GN_OK only: 2 x 1 KiB affine tables (see igemm_halo_kernel)
+  // GroupNorm apply fused into the loader: one image per tile only (the 8x8x4 shape has no LDS left for the tables)
+  constexpr bool GN_OK = NIMG == 1 && HSLOTS <= 7;
+  const bool gnp = GN_OK && p.gn_ab != nullptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid % WM, wn = wid / WM;
@@ -1499,6 +1503,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
     const uint16_t* g = hpix[t] >= 0 ? src + hpix[t] * ld + cc : zero;
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(hbuf + (c & 1) * HBYTES + q * 1024), 16, 0, 0);
   };
+  auto issue_ab = [&](int c) {                            // affine table of chunk c -> abuf[c & 1] (see igemm_halo_kernel)
+    const float* t = p.gn_ab + ((long long)img0 * 2 + (lane >> 4 & 1)) * p.Cin + (c_begin + c) * 64 + (lane & 15) * 4;
+    const void* g = lane < 32 ? (const void*)t : (const void*)zero;
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (c & 1) * 1024), 16, 0, 0);
+  };
+  auto gn_slot = [&](int c, int t) {                      // this wave's halo piece t of chunk c, in place (per-piece chunk here)
+    if (hpix[t] >= 0)
+      gn_piece_inplace<F16>(hbuf + (c & 1) * HBYTES + (t * NW + wid) * 1024 + lane * 16, abuf + (c & 1) * 1024, hchk[t], p.gn_silu != 0);
+  };
 
   f32x16 acc[FN][FM];
 #pragma unroll
@@ -1519,6 +1532,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
     hy0[b] = y;
   }
 
+  if (gnp) issue_ab(0);
 #pragma unroll
   for (int t = 0; t < HSLOTS; ++t) issue_h(0, t);
   issue_w(0, 0);
@@ -1527,6 +1541,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (gnp) {
+#pragma unroll
+    for (int t = 0; t < HSLOTS; ++t) gn_slot(0, t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
 
@@ -1540,6 +1559,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
       const bool more_h = tap < HSLOTS && next_chunk;
       if (more_w) issue_w(kt + 2, (tap + 2) % 3);
       if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
+      const bool ab_now = gnp && tap == 0 && next_chunk;
+      if (ab_now) issue_ab(c + 1);
+      if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
@@ -1585,9 +1607,11 @@ template <int TH, int TW, int NIMG, int BN, int WM, int WN>
 int launch_halo_img(ConvK& k, hipStream_t s) {
   constexpr int NW = WM * WN, BM = TH * TW * NIMG, HPIX = (TH + 2) * (TW + 2) * NIMG, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
   constexpr int HBYTES = HSLOTS * NW * 1024;
-  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128, lds_epi = epi_lds_bytes<BM, BN, NW * 64>();
+  constexpr bool GN_OK = NIMG == 1 && HSLOTS <= 7;          // must match the kernel's
+  constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128 + (GN_OK ? 2048 : 0), lds_epi = epi_lds_bytes<BM, BN, NW * 64>();
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
+  k.prologue_ok = GN_OK ? 1 : 0;
   k.tiles_m = (k.N + NIMG - 1) / NIMG;
   k.tiles_n = (k.Cout + BN - 1) / BN;
   const int nchunk = k.nk / 9;

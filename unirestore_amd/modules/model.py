@@ -384,11 +384,15 @@ class DiffUIE(nn.Module):
         ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
         noise = torch.randn_like(latents) if noise is None else noise.to(DEV).float()
         ac = schedule.alphas_cumprod()
+        lat = latents.shape[1]
+        # fp32 throughout (the latent state never passes through a 16-bit tensor): NHWC fp32 padded to 8 channels for the kernel
+        z = F.pad(latents.permute(0, 2, 3, 1), (0, 8 - lat)).contiguous()
         outs = []
         for i, t in enumerate(ts):       # per-sample t (training helper); inference uses one t for the batch
-            z = ops.nchw_to_nhwc(latents[i:i + 1]).float().contiguous()
-            zt, _ = ops.add_noise(z, noise[i:i + 1].contiguous(), latents.shape[1], float(ac[t]) ** 0.5, float(1 - ac[t]) ** 0.5)
-            outs.append(ops.nhwc_to_nchw(zt, c=latents.shape[1]))
+            a_t = np.float32(float(ac[t]))
+            sa, sb = float(np.sqrt(a_t)), float(np.sqrt(np.float32(1) - a_t))          # fp32 sqrt, as DDPMScheduler.add_noise
+            zt, _ = ops.add_noise(z[i:i + 1].contiguous(), noise[i:i + 1].contiguous(), lat, sa, sb)
+            outs.append(ops.nhwc_to_nchw(zt, c=lat))
         return torch.cat(outs, 0), noise, torch.as_tensor(ts)
 
     # ---- the hot path ------------------------------------------------------------------------------------------------

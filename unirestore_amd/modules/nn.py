@@ -249,15 +249,20 @@ def self_attention(mod, h, heads, residual, gn_kw={}, ln=None, rows=False):
     return ops.linear(o, mod.to_out[0].packed(), residual=residual, rows=rows, **gn_kw)
 
 
-def attention_gemm(q, k, vt, heads, d, t):
-    """Large-head-dim attention (VAE mid block: 1 head x 512) as S = QK^T (fp32) -> row softmax -> P V."""
+def attention_gemm(q, k, vt, heads, d, t, s_bytes=256 << 20):
+    """Large-head-dim attention (VAE mid block: 1 head x 512) as S = QK^T (fp32) -> row softmax -> P V, in QUERY CHUNKS so
+    that the fp32 score block stays bounded (<= s_bytes = 256 MB, instead of B x T x T x 4 = 1 GiB per image at 1024x1024)."""
     b = q.shape[0]
-    outs = []
+    rows = max(256, min(t, (s_bytes // (4 * b * t)) // 256 * 256))
+    out = torch.empty((b, t, heads * d), dtype=q.dtype, device=q.device)
     for hh in range(heads):
-        s = ops.bmm_nt(q[:, :, hh * d:(hh + 1) * d], k[:, :, hh * d:(hh + 1) * d], out_f32=True, out_scale=1.0 / math.sqrt(d))
-        p = ops.softmax_rows(s, ldp=vt.shape[-1])
-        outs.append(ops.bmm_nt(p, vt[:, hh * d:(hh + 1) * d, :]))
-    return outs[0] if heads == 1 else torch.cat(outs, -1)
+        qh, kh, vh = q[:, :, hh * d:(hh + 1) * d], k[:, :, hh * d:(hh + 1) * d], vt[:, hh * d:(hh + 1) * d, :]
+        for r0 in range(0, t, rows):
+            r1 = min(t, r0 + rows)
+            s = ops.bmm_nt(qh[:, r0:r1], kh, out_f32=True, out_scale=1.0 / math.sqrt(d))
+            p = ops.softmax_rows(s, ldp=vt.shape[-1])
+            out[:, r0:r1, hh * d:(hh + 1) * d] = ops.bmm_nt(p, vh)
+    return out
 
 
 class AttentionBlock(nn.Module):
