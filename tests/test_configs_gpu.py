@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # measured rel-L2 (z0, zt, image) on MI355X x 1.5, full-size random-weight model
-TOL = {"bf16": (9e-3, 7e-3, 7e-3), "fp16": (1.2e-3, 1e-3, 1e-3)}
+# measured (r2): bf16 z0 5.4-5.7e-3, zt 3.1-4.0e-3, image 3.9-4.2e-3; fp16 z0 7.3-7.6e-4, zt 6.3-8.3e-4, image 5.2-5.7e-4
+TOL = {"bf16": (8.5e-3, 6.1e-3, 6.3e-3), "fp16": (1e-3, 1e-3, 1e-3)}      # fp16: the north-star bar itself
 
 
 def _kw(steps):
@@ -39,7 +40,6 @@ def full():
     m = bench.build_model(1, dev, 0, 1)
     o = ODiffUIE(**_kw(1)).eval()
     o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
-    torch.set_num_threads(os.cpu_count() or 8)
     return o, m
 
 
@@ -111,25 +111,24 @@ def test_config4_fifty_steps_fp16_full_size(full):
     m.set_dtype("bf16")
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_config4_fifty_steps_parity_tiny(dtype):
-    """50-step DDIM trajectory against the oracle (tiny configuration, where the oracle takes seconds)."""
+def test_config4_fifty_steps_parity_tiny():
+    """50-step DDIM trajectory against the oracle (tiny configuration, where the oracle takes ~90 s), both 16-bit types."""
     from oracle.model import DiffUIE as ODiffUIE
     from tiny_cfg import TINY, model_kwargs, randomise_
     import unirestore_amd.modules as M
     o = randomise_(ODiffUIE(**model_kwargs(50), **TINY).eval(), 11)
-    p = M.DiffUIE(**model_kwargs(50), **TINY, dtype=dtype).eval()
-    p.load_state_dict(o.state_dict())
-    assert p.timesteps.tolist() == list(range(999, 0, -20))
     g = torch.Generator().manual_seed(47)
     img = torch.rand(2, 3, 64, 64, generator=g)
     nz = (torch.randn(2, 4, 64, 64, generator=g), torch.randn(2, 4, 64, 64, generator=g))
     oy = o(img, "ir", noise=nz, return_latents=True)
-    py = p(img, "ir", noise=nz, return_latents=True)
-    e = [rel_l2(a.cpu(), b) for a, b in zip(py, oy)]
-    print(f"50-step tiny [{dtype}] rel-L2 image {e[0]:.2e} z0 {e[1]:.2e} zt {e[2]:.2e}")
-    lim = 1.2e-2 if dtype == "bf16" else 1.5e-3               # 50 steps accumulate: measured bf16 ~8e-3, fp16 ~1e-3
-    assert max(e) < lim, e
+    for dtype, lim in (("bf16", 7.6e-3), ("fp16", 1.2e-3)):   # 1.5 x measured (bf16 5.0e-3 on z0, fp16 8.0e-4)
+        p = M.DiffUIE(**model_kwargs(50), **TINY, dtype=dtype).eval()
+        p.load_state_dict(o.state_dict())
+        assert p.timesteps.tolist() == list(range(999, 0, -20))
+        py = p(img, "ir", noise=nz, return_latents=True)
+        e = [rel_l2(a.cpu(), b) for a, b in zip(py, oy)]
+        print(f"50-step tiny [{dtype}] rel-L2 image {e[0]:.2e} z0 {e[1]:.2e} zt {e[2]:.2e}")
+        assert max(e) < lim, (dtype, e)
 
 
 def test_cli_validate_config0():
