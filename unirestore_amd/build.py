@@ -16,7 +16,8 @@ LIB = os.path.join(HERE, "libunirestore_hip.so")
 IGEMM_UNITS = ["igemm_v2.hip", "igemm_halo.hip", "igemm_v1a.hip", "igemm_v1b.hip", "igemm_g1.hip"]     # slowest first
 # (source, extra flags, object name): every igemm instantiation unit is built once per 16-bit type
 SOURCES = [(u, [f"-DUR_TU_F16={t}"], u.replace(".hip", "_f16.o" if t else "_bf16.o")) for u in IGEMM_UNITS for t in (0, 1)] + \
-          [(u, [], u.replace(".hip", ".o")) for u in ("igemm.hip", "attention.hip", "norms.hip", "elementwise.hip", "runtime.hip")]
+          [("attention.hip", [f"-DUR_TU_F16={t}"], "attention_f16.o" if t else "attention_bf16.o") for t in (0, 1)] + \
+          [(u, [], u.replace(".hip", ".o")) for u in ("igemm.hip", "norms.hip", "elementwise.hip", "runtime.hip")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-Wno-unused-result"]
 

@@ -51,12 +51,13 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
   const uint16_t* V = p.vt + b * p.bs_vt + (long long)h * D * p.ldvt;
 
   // Q fragments (B operand): lane -> query q0 + l31, dims ds*16 + hf*8 .. +7
-  uint4 qf[DS];
+  typedef typename Frag<F16>::type frag_t;
+  frag_t qf[DS];
   {
     const int qi = min(q0 + l31, p.Tq - 1);
     const uint16_t* qp = Q + (long long)qi * p.ldq + hf * 8;
 #pragma unroll
-    for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const uint4*>(qp + ds * 16);
+    for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const frag_t*>(qp + ds * 16);
   }
 
   // K / V^T tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1-KiB piece = 8 rows x 128 B per wave
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
       const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
 #pragma unroll
       for (int ds = 0; ds < DS; ++ds) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(ks + row * KROW + (((ds * 2 + hf) ^ sw) << 4));
-        sacc[f] = mfma16<F16>(kf, qf[ds], sacc[f]);
+        const frag_t kf = *reinterpret_cast<const frag_t*>(ks + row * KROW + (((ds * 2 + hf) ^ sw) << 4));
+        sacc[f] = mfma16t(kf, qf[ds], sacc[f]);
       }
     }
     // register r of fragment f, half hf  <->  key  t*64 + f*32 + 16*(r>>3) + 8*hf + (r&7)
@@ -203,11 +204,12 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
       const float* sp = s + kk * 8;
       pk.x = Act<F16>::pack2(sp[0], sp[1]); pk.y = Act<F16>::pack2(sp[2], sp[3]);
       pk.z = Act<F16>::pack2(sp[4], sp[5]); pk.w = Act<F16>::pack2(sp[6], sp[7]);
+      const frag_t pf = __builtin_bit_cast(frag_t, pk);
 #pragma unroll
       for (int f = 0; f < DF; ++f) {
         const int row = f * 32 + l31;
-        const uint4 vf = *reinterpret_cast<const uint4*>(vs + row * 128 + (((kk * 2 + hf) ^ ((row >> 1) & 7)) << 4));
-        oacc[f] = mfma16<F16>(vf, pk, oacc[f]);
+        const frag_t vf = *reinterpret_cast<const frag_t*>(vs + row * 128 + (((kk * 2 + hf) ^ ((row >> 1) & 7)) << 4));
+        oacc[f] = mfma16t(vf, pf, oacc[f]);
       }
     }
     if (more) store_tile(stage ^ 1);
@@ -235,6 +237,39 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
 
 }  // namespace
 
+// Built twice (-DUR_TU_F16=0 / 1), one object per 16-bit type: instantiations of one kernel template that share a translation
+// unit perturb each other's register allocation (the bf16 kernel measured 8 % slower next to its fp16 twin).
+#ifndef UR_TU_F16
+#define UR_TU_F16 0
+#endif
+#if UR_TU_F16
+#define UR_ATTN_LAUNCH ur_attn_launch_f16
+#else
+#define UR_ATTN_LAUNCH ur_attn_launch_bf16
+#endif
+int ur_attn_launch_bf16(const void* pp, int D, hipStream_t s);
+int ur_attn_launch_f16(const void* pp, int D, hipStream_t s);
+
+int UR_ATTN_LAUNCH(const void* pp, int D, hipStream_t s) {
+  const AttnP& p = *static_cast<const AttnP*>(pp);
+  constexpr bool F16 = UR_TU_F16 != 0;
+  dim3 grid((p.Tq + 127) / 128, p.B * p.H), block(256);
+  if (D == 64) {
+    constexpr int lds = 2 * (64 * 128 + 64 * 128);
+    hipLaunchKernelGGL((attn_fwd_kernel<64, F16>), grid, block, lds, s, p);
+  } else {
+    constexpr int lds = 2 * (64 * 256 + 128 * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<128, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<128, F16>), grid, block, lds, s, p);
+  }
+  return ur::check_launch("ur_attention_fwd");
+}
+
+#if !UR_TU_F16
 extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk, int D,
                                 int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k, long long bs_vt,
                                 long long bs_o, float scale, int dtype, ur_stream_t stream) {
@@ -252,19 +287,6 @@ extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, vo
   const double flops = 4.0 * B * H * (double)Tq * Tk * D;
   const double bytes = 2.0 * B * H * ((double)Tq * D * 2 + (double)Tk * D * 2);
   ur::ProfScope prof("attention", flops, bytes, s);
-  dim3 grid((Tq + 127) / 128, B * H), block(256);
-  if (D == 64) {
-    constexpr int lds = 2 * (64 * 128 + 64 * 128);
-    UR_DT_SWITCH(dtype, hipLaunchKernelGGL((attn_fwd_kernel<64, F16>), grid, block, lds, s, p));
-  } else {
-    constexpr int lds = 2 * (64 * 256 + 128 * 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
-    }
-    UR_DT_SWITCH(dtype, hipLaunchKernelGGL((attn_fwd_kernel<128, F16>), grid, block, lds, s, p));
-  }
-  return ur::check_launch("ur_attention_fwd");
+  return dtype == UR_DT_F16 ? ur_attn_launch_f16(&p, D, s) : ur_attn_launch_bf16(&p, D, s);
 }
+#endif

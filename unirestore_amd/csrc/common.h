@@ -61,6 +61,12 @@ template <bool F16> __device__ __forceinline__ void unpack8t(const uint4& v, flo
 template <bool F16> __device__ __forceinline__ uint4 pack8t(const float* f) {
   return make_uint4(Act<F16>::pack2(f[0], f[1]), Act<F16>::pack2(f[2], f[3]), Act<F16>::pack2(f[4], f[5]), Act<F16>::pack2(f[6], f[7]));
 }
+// typed 8-element fragments (the element type reaches the IR: with raw uint4 fragments hipcc scheduled the halo conv's tap loop
+// with 35 % more s_waitcnt instructions between the MFMAs and the kernel ran 7-10 % slower)
+template <bool F16> struct Frag { typedef bf16x8 type; };
+template <> struct Frag<true> { typedef f16x8 type; };
+__device__ __forceinline__ f32x16 mfma16t(const bf16x8& a, const bf16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16t(const f16x8& a, const f16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 // one 32x32x16 MFMA step on 16-bit operands held as raw 128-bit fragments
 template <bool F16> __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, const f32x16& c) {
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);

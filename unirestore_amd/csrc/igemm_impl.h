@@ -570,22 +570,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int slot = ks * 2 + fhalf;
-      uint4 bfr[FM], afr[FN];
+      typename Frag<F16>::type bfr[FM], afr[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
         int row = wm * WTM + b * 32 + frow;
-        bfr[b] = *reinterpret_cast<const uint4*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        bfr[b] = *reinterpret_cast<const typename Frag<F16>::type*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
         int row = wn * WTN + a * 32 + frow;
-        afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        afr[a] = *reinterpret_cast<const typename Frag<F16>::type*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b)
-          acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
+          acc[a][b] = mfma16t(afr[a], bfr[b], acc[a][b]);
     }
   };
 
@@ -979,22 +979,22 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int slot = ks * 2 + fhalf;
-      uint4 bfr[FM], afr[FN];
+      typename Frag<F16>::type bfr[FM], afr[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
         int row = wm * WTM + b * 32 + frow;
-        bfr[b] = *reinterpret_cast<const uint4*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        bfr[b] = *reinterpret_cast<const typename Frag<F16>::type*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
         int row = wn * WTN + a * 32 + frow;
-        afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        afr[a] = *reinterpret_cast<const typename Frag<F16>::type*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b)
-          acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
+          acc[a][b] = mfma16t(afr[a], bfr[b], acc[a][b]);
     }
   };
 
@@ -1100,22 +1100,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int slot = ks * 2 + fhalf;
-      uint4 bfr[FM], afr[FN];
+      typename Frag<F16>::type bfr[FM], afr[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
         const int row = wm * WTM + b * 32 + frow;
-        bfr[b] = *reinterpret_cast<const uint4*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        bfr[b] = *reinterpret_cast<const typename Frag<F16>::type*>(xs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
         const int row = wn * WTN + a * 32 + frow;
-        afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        afr[a] = *reinterpret_cast<const typename Frag<F16>::type*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b)
-          acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
+          acc[a][b] = mfma16t(afr[a], bfr[b], acc[a][b]);
     }
     cs = (cs + 1 == NST) ? 0 : cs + 1;
     if (NST >= 3 && issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
@@ -1178,10 +1178,16 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
 // GroupNorm apply (+ SiLU) on one 16-byte piece of an LDS-resident input patch, in place: 8 channels of one pixel,
 // v <- act(a[c] * v + b[c]) with (a, b) taken from the LDS copy of this chunk's affine table (fp32 a[64] | b[64], the table
 // ur_groupnorm_finalize produced).  Zero-padding pieces are never touched (the convolution pads the NORMALISED tensor).
+struct GnAB { float4 a0, a1, b0, b1; };
+__device__ __forceinline__ GnAB gn_load_ab(const unsigned char* abuf, int chunk) {
+  GnAB r;
+  r.a0 = *reinterpret_cast<const float4*>(abuf + chunk * 32); r.a1 = *reinterpret_cast<const float4*>(abuf + chunk * 32 + 16);
+  r.b0 = *reinterpret_cast<const float4*>(abuf + 256 + chunk * 32); r.b1 = *reinterpret_cast<const float4*>(abuf + 256 + chunk * 32 + 16);
+  return r;
+}
 template <bool F16>
-__device__ __forceinline__ void gn_piece_inplace(unsigned char* piece, const unsigned char* abuf, int chunk, bool silu) {
-  const float4 a0 = *reinterpret_cast<const float4*>(abuf + chunk * 32), a1 = *reinterpret_cast<const float4*>(abuf + chunk * 32 + 16);
-  const float4 b0 = *reinterpret_cast<const float4*>(abuf + 256 + chunk * 32), b1 = *reinterpret_cast<const float4*>(abuf + 256 + chunk * 32 + 16);
+__device__ __forceinline__ void gn_piece_inplace(unsigned char* piece, const GnAB& ab, bool silu) {
+  const float4 a0 = ab.a0, a1 = ab.a1, b0 = ab.b0, b1 = ab.b1;
   const uint4 v = *reinterpret_cast<const uint4*>(piece);
   float f[8];
   unpack8t<F16>(v, f);
@@ -1204,7 +1210,7 @@ __device__ __forceinline__ void gn_piece_inplace(unsigned char* piece, const uns
 // K tile (3-stage ring).  Ingest per K tile drops from (256+BN)*128 B to ~BN*128 B + 5 KB.
 // A fragment is one 32-pixel patch row, so its LDS rows are consecutive for every tap and the (row>>1)&7 slot swizzle
 // stays conflict-free (tools/lds_conflicts.py model; a 16x16 patch would be 2-way conflicted on every tap).
-template <int TH, int BN, int WM, int WN, bool F16>
+template <int TH, int BN, int WM, int WN, bool F16, bool GNP>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) {
   constexpr int NW = WM * WN, TW = 32, BM = TH * TW, PW = TW + 2, HPIX = (TH + 2) * PW;   // 340 (TH=8) / 204 (TH=4) halo pixels
   constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);                              // tap slots that carry a halo piece
@@ -1218,7 +1224,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
   unsigned char* const abuf = wring + 3 * WBYTES;        // 2 x 1 KiB: GroupNorm affine (a[64] | b[64]) of the current / next chunk
   // GroupNorm apply (+ SiLU) of the input fused into the loader (ur_conv_desc.gn_ab): every wave rewrites the halo pieces IT
   // fetched, in LDS, two taps after issuing them (its own vmcnt covers them) - the normalised tensor never exists in HBM.
-  const bool gnp = p.gn_ab != nullptr;
+  // (GNP is a compile-time variant: with a run-time flag the plain kernel's tap loop scheduled 20 % slower)
+  constexpr bool gnp = GNP;
+  const bool gn_early = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < (WM * WN) / 2;
   static_assert(HSLOTS <= 7, "the in-LDS GroupNorm pass needs taps 2 .. HSLOTS+1 <= 8");
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1294,9 +1302,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     const void* g = lane < 32 ? (const void*)t : (const void*)zero;
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (c & 1) * 1024), 16, 0, 0);
   };
+  GnAB gab;                                               // this lane's 8 channels of the chunk being normalised (chunk is lane-constant)
   auto gn_slot = [&](int c, int t) {                      // this wave's halo piece t of chunk c, in place
-    if (hpix[t] >= 0)
-      gn_piece_inplace<F16>(hbuf + (c & 1) * HBYTES + (t * NW + wid) * 1024 + lane * 16, abuf + (c & 1) * 1024, chunk, p.gn_silu != 0);
+    if (t == 0) gab = gn_load_ab(abuf + (c & 1) * 1024, chunk);
+    if (hpix[t] >= 0) gn_piece_inplace<F16>(hbuf + (c & 1) * HBYTES + (t * NW + wid) * 1024 + lane * 16, gab, p.gn_silu != 0);
   };
 
   f32x16 acc[FN][FM];
@@ -1341,33 +1350,36 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
       if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
       const bool ab_now = gnp && tap == 0 && next_chunk;    // (+1 DMA op in this iteration, counted in the wait below)
       if (ab_now) issue_ab(c + 1);
-      // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it under this tap's MFMAs
-      if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
+      // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it in LDS.  The two waves that share
+      // a SIMD (w, w + NW/2) do it on opposite sides of the tap's MFMA block, so one's VALU work runs under the other's MFMAs.
+      const bool gn_now = gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk;
+      if (gn_now && gn_early) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const int slot = ks * 2 + fhalf;
-          uint4 bfr[FM], afr[FN];
+          typename Frag<F16>::type bfr[FM], afr[FN];
 #pragma unroll
           for (int b = 0; b < FM; ++b) {
             const int hrow = (wm * FM + b + dy) * PW + dx + frow;
-            bfr[b] = *reinterpret_cast<const uint4*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
+            bfr[b] = *reinterpret_cast<const typename Frag<F16>::type*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
           }
 #pragma unroll
           for (int a = 0; a < FN; ++a) {
             const int row = wn * WTN + a * 32 + frow;
-            afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+            afr[a] = *reinterpret_cast<const typename Frag<F16>::type*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
           }
 #pragma unroll
           for (int a = 0; a < FN; ++a)
 #pragma unroll
             for (int b = 0; b < FM; ++b)
-              acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
+              acc[a][b] = mfma16t(afr[a], bfr[b], acc[a][b]);
         }
       }
       // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
+      if (gn_now && !gn_early) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       if (ab_now) {                                       // tap 0 with the next chunk's affine table in flight as well
         if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -1408,10 +1420,12 @@ int launch_halo(ConvK& k, hipStream_t s) {
   k.patch_tw = 32;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
+  if (k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, true>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
+  else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
   if (k.splitk > 1) {
     k.patch_tw = 0;                                        // the partial planes are plain [M][Cout]
     launch_splitk_reduce(k, s);
@@ -1427,7 +1441,7 @@ int launch_halo(ConvK& k, hipStream_t s) {
 // because these layers have few tiles and K = 9 x 1280..2560.  A 32-pixel fragment spans several image rows; the slot
 // swizzle f(row) = ((row_in_image >> 1) - halo_y) & 7 keeps its ds_read_b128 conflict-free for both shapes
 // (searched with tools/lds_conflicts.py), at the price of a per-piece source chunk on the DMA side.
-template <int TH, int TW, int NIMG, int BN, int WM, int WN, bool F16>
+template <int TH, int TW, int NIMG, int BN, int WM, int WN, bool F16, bool GNP>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK p) {
   constexpr int NW = WM * WN, BM = TH * TW * NIMG, PW = TW + 2, HP = (TH + 2) * PW, HPIX = HP * NIMG;
   constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
@@ -1441,7 +1455,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
   unsigned char* const abuf = wring + 3 * WBYTES;        // GN_OK only: 2 x 1 KiB affine tables (see igemm_halo_kernel)
   // GroupNorm apply fused into the loader: one image per tile only (the 8x8x4 shape has no LDS left for the tables)
   constexpr bool GN_OK = NIMG == 1 && HSLOTS <= 7;
-  const bool gnp = GN_OK && p.gn_ab != nullptr;
+  constexpr bool gnp = GN_OK && GNP;
+  const bool gn_early = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < (WM * WN) / 2;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid % WM, wn = wid / WM;
@@ -1510,7 +1525,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
   };
   auto gn_slot = [&](int c, int t) {                      // this wave's halo piece t of chunk c, in place (per-piece chunk here)
     if (hpix[t] >= 0)
-      gn_piece_inplace<F16>(hbuf + (c & 1) * HBYTES + (t * NW + wid) * 1024 + lane * 16, abuf + (c & 1) * 1024, hchk[t], p.gn_silu != 0);
+      gn_piece_inplace<F16>(hbuf + (c & 1) * HBYTES + (t * NW + wid) * 1024 + lane * 16, gn_load_ab(abuf + (c & 1) * 1024, hchk[t]), p.gn_silu != 0);
   };
 
   f32x16 acc[FN][FM];
@@ -1561,7 +1576,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
       if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
       const bool ab_now = gnp && tap == 0 && next_chunk;
       if (ab_now) issue_ab(c + 1);
-      if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
+      // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it in LDS.  The two waves that share
+      // a SIMD (w, w + NW/2) do it on opposite sides of the tap's MFMA block, so one's VALU work runs under the other's MFMAs.
+      const bool gn_now = gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk;
+      if (gn_now && gn_early) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
@@ -1574,21 +1592,22 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const int slot = ks * 2 + fhalf;
-          uint4 bfr[FM], afr[FN];
+          typename Frag<F16>::type bfr[FM], afr[FN];
 #pragma unroll
-          for (int b = 0; b < FM; ++b) bfr[b] = *reinterpret_cast<const uint4*>(hb + hro[b] + ((slot ^ hsw[b]) << 4));
+          for (int b = 0; b < FM; ++b) bfr[b] = *reinterpret_cast<const typename Frag<F16>::type*>(hb + hro[b] + ((slot ^ hsw[b]) << 4));
 #pragma unroll
           for (int a = 0; a < FN; ++a) {
             const int row = wn * WTN + a * 32 + frow;
-            afr[a] = *reinterpret_cast<const uint4*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+            afr[a] = *reinterpret_cast<const typename Frag<F16>::type*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
           }
 #pragma unroll
           for (int a = 0; a < FN; ++a)
 #pragma unroll
             for (int b = 0; b < FM; ++b)
-              acc[a][b] = mfma16<F16>(afr[a], bfr[b], acc[a][b]);
+              acc[a][b] = mfma16t(afr[a], bfr[b], acc[a][b]);
         }
       }
+      if (gn_now && !gn_early) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       if (ab_now) {                                       // tap 0 with the next chunk's affine table in flight as well
         if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -1628,10 +1647,12 @@ int launch_halo_img(ConvK& k, hipStream_t s) {
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
+  if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
+  else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
   if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
 }

@@ -80,14 +80,20 @@ __global__ void gn_finalize_kernel(const float* __restrict__ p1, int P1, int C1,
       s += (double)v.x; q += (double)v.y;
     }
   }
-  red[0][t] = s; red[1][t] = q;
-  __syncthreads();
-  for (int o = NT >> 1; o > 0; o >>= 1) {
-    if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; }
+  if (NT == 64) {            // one wave: fixed butterfly through the lanes, no LDS round trips (every lane ends with the total)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  } else {
+    red[0][t] = s; red[1][t] = q;
     __syncthreads();
+    for (int o = NT >> 1; o > 0; o >>= 1) {
+      if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; }
+      __syncthreads();
+    }
   }
-  const double mean = red[0][0] * inv_cnt;
-  const double var = fma(red[1][0], inv_cnt, -mean * mean);
+  const double S = NT == 64 ? s : red[0][0], Q = NT == 64 ? q : red[1][0];
+  const double mean = S * inv_cnt;
+  const double var = fma(Q, inv_cnt, -mean * mean);
   const float rstd = rsqrtf(fmaxf((float)var, 0.f) + eps);
   if (mean_out && t == 0) mean_out[(long long)n * G + g] = (float)mean;
   if (ab)
@@ -291,7 +297,7 @@ int ur_groupnorm_finalize(const float* part1, int parts1, int C1, const float* p
   const int cpg = C / G;
   const long long entries = (long long)cpg * std::max(parts1, part2 ? parts2 : 0);
   ur::ProfScope prof("groupnorm_finalize", 0.0, 8.0 * N * ((double)parts1 * C1 + (part2 ? (double)parts2 * C2 : 0.0)), s);
-  const int nt = entries <= 64 ? 64 : 256;
+  const int nt = entries <= 1024 ? 64 : 256;            // <= 16 entries per lane: one wave, shuffle reduction
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(nt), 0, s, part1, parts1, C1, part2, part2 ? parts2 : 0, part2 ? C2 : 0, gamma, beta, G,
                      eps, 1.0 / ((double)cpg * HW), ab, mean_out);
   return ur::check_launch("ur_groupnorm_finalize");
