@@ -408,10 +408,10 @@ def test_conv1x1_virtual_concat_shortcuts(ops, n, hw, c1, c2, cout):
 
 
 @pytest.mark.parametrize("n,c1,c2,cout,h,w,ups", [(8, 128, 0, 256, 32, 64, False),       # 8x32 halo patches, 128 tiles
-                                                  (4, 320, 320, 320, 32, 64, False),     # virtual concat, 160-wide tiles
-                                                  (8, 64, 0, 160, 16, 32, True),         # fused nearest-2x upsample
+                                                  (4, 320, 320, 256, 32, 64, False),     # virtual concat
+                                                  (8, 64, 0, 128, 16, 32, True),         # fused nearest-2x upsample
                                                   (8, 256, 0, 128, 32, 64, False),       # 64 tiles -> channel-chunk split + reduce pass
-                                                  (8, 128, 64, 160, 24, 96, False),      # concat boundary inside the K range
+                                                  (8, 128, 64, 128, 24, 96, False),      # concat boundary inside the K range
                                                   (3, 256, 0, 128, 16, 16, False), (2, 640, 640, 256, 16, 16, False)])   # 16x16 whole-image tiles
 def test_conv_groupnorm_prologue(ops, n, c1, c2, cout, h, w, ups):
     """GroupNorm apply + SiLU fused into the 3x3 conv's loader (ur_conv_desc.gn_ab: halo 8x32 patches and 16x16 whole-image

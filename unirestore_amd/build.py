@@ -12,7 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libunirestore_hip.so")
+LIB = os.environ.get("UR_LIB_OUT") or os.path.join(HERE, "libunirestore_hip.so")      # UR_LIB_OUT / UR_EXTRA_FLAGS: A/B builds
+EXTRA = os.environ.get("UR_EXTRA_FLAGS", "").split()
 IGEMM_UNITS = ["igemm_v2.hip", "igemm_halo.hip", "igemm_v1a.hip", "igemm_v1b.hip", "igemm_g1.hip"]     # slowest first
 # (source, extra flags, object name): every igemm instantiation unit is built once per 16-bit type
 SOURCES = [(u, [f"-DUR_TU_F16={t}"], u.replace(".hip", "_f16.o" if t else "_bf16.o")) for u in IGEMM_UNITS for t in (0, 1)] + \
@@ -40,14 +41,21 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if not EXTRA else "build_" + "_".join(f.strip("-").replace("=", "") for f in EXTRA))
     os.makedirs(objdir, exist_ok=True)
     cc = _hipcc()
 
     def one(unit):
         src, extra, oname = unit
         obj = os.path.join(objdir, oname)
-        cmd = [cc, *FLAGS, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *FLAGS, *EXTRA, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
+        deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "unirestore_hip.h")]
+        if src.startswith("igemm"):
+            deps.append(os.path.join(CSRC, "igemm_impl.h"))
+        newest = max(os.path.getmtime(d) for d in deps)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest and os.path.exists(obj + ".usage"):
+            usage.update(json.load(open(obj + ".usage")))          # unchanged since this object was built
+            return obj
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -60,6 +68,7 @@ def build(force=False, verbose=True):
             m = re.search(r"(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
             if m and name:
                 usage.setdefault(f"{oname}:{name}", {})[m.group(1).split(" ")[0]] = int(m.group(2))
+        json.dump({k: v for k, v in usage.items() if k.startswith(oname + ":")}, open(obj + ".usage", "w"))
         return obj
 
     usage = {}

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunirestore_hip.so")
+LIB_PATH = os.environ.get("UR_LIB") or os.path.join(_HERE, "libunirestore_hip.so")     # UR_LIB: an A/B build of the same ABI
 
 UR_ACT_NONE, UR_ACT_SILU, UR_ACT_GELU, UR_ACT_GEGLU, UR_ACT_GATE, UR_ACT_TANH, UR_ACT_RELU = range(7)
 UR_DT_BF16, UR_DT_F16 = 0, 1

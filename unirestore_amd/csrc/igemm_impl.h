@@ -1226,7 +1226,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
   // fetched, in LDS, two taps after issuing them (its own vmcnt covers them) - the normalised tensor never exists in HBM.
   // (GNP is a compile-time variant: with a run-time flag the plain kernel's tap loop scheduled 20 % slower)
   constexpr bool gnp = GNP;
-  const bool gn_early = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < (WM * WN) / 2;
   static_assert(HSLOTS <= 7, "the in-LDS GroupNorm pass needs taps 2 .. HSLOTS+1 <= 8");
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1302,10 +1301,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     const void* g = lane < 32 ? (const void*)t : (const void*)zero;
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (c & 1) * 1024), 16, 0, 0);
   };
-  GnAB gab;                                               // this lane's 8 channels of the chunk being normalised (chunk is lane-constant)
   auto gn_slot = [&](int c, int t) {                      // this wave's halo piece t of chunk c, in place
-    if (t == 0) gab = gn_load_ab(abuf + (c & 1) * 1024, chunk);
-    if (hpix[t] >= 0) gn_piece_inplace<F16>(hbuf + (c & 1) * HBYTES + (t * NW + wid) * 1024 + lane * 16, gab, p.gn_silu != 0);
+    if (hpix[t] >= 0)
+      gn_piece_inplace<F16>(hbuf + (c & 1) * HBYTES + (t * NW + wid) * 1024 + lane * 16, gn_load_ab(abuf + (c & 1) * 1024, chunk), p.gn_silu != 0);
   };
 
   f32x16 acc[FN][FM];
@@ -1350,27 +1348,30 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
       if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
       const bool ab_now = gnp && tap == 0 && next_chunk;    // (+1 DMA op in this iteration, counted in the wait below)
       if (ab_now) issue_ab(c + 1);
-      // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it in LDS.  The two waves that share
-      // a SIMD (w, w + NW/2) do it on opposite sides of the tap's MFMA block, so one's VALU work runs under the other's MFMAs.
-      const bool gn_now = gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk;
-      if (gn_now && gn_early) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
+      // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it in LDS next to this tap's MFMAs
+      // (splitting the two waves of a SIMD to opposite sides of the MFMA block measured no gain and cost registers)
+      if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        typedef typename Frag<F16>::type frag_t;
+        auto load_frags = [&](int ks, frag_t (&bfr)[FM], frag_t (&afr)[FN]) {
           const int slot = ks * 2 + fhalf;
-          typename Frag<F16>::type bfr[FM], afr[FN];
 #pragma unroll
           for (int b = 0; b < FM; ++b) {
             const int hrow = (wm * FM + b + dy) * PW + dx + frow;
-            bfr[b] = *reinterpret_cast<const typename Frag<F16>::type*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
+            bfr[b] = *reinterpret_cast<const frag_t*>(hb + hrow * 128 + ((slot ^ ((hrow >> 1) & 7)) << 4));
           }
 #pragma unroll
           for (int a = 0; a < FN; ++a) {
             const int row = wn * WTN + a * 32 + frow;
-            afr[a] = *reinterpret_cast<const typename Frag<F16>::type*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+            afr[a] = *reinterpret_cast<const frag_t*>(wsm + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
           }
+        };
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          frag_t bfr[FM], afr[FN];
+          load_frags(ks, bfr, afr);
 #pragma unroll
           for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -1379,7 +1380,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
         }
       }
       // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
-      if (gn_now && !gn_early) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       if (ab_now) {                                       // tap 0 with the next chunk's affine table in flight as well
         if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -1401,7 +1401,9 @@ int launch_halo(ConvK& k, hipStream_t s) {
   constexpr int lds_loop = 2 * HBYTES + 3 * BN * 128 + 2048, lds_epi = epi_lds_bytes<BM, BN, NW * 64>();     // (+ 2 x 1 KiB affine tables)
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  k.prologue_ok = 1;
+  // in-loader GroupNorm: the 128-wide tile only (the 160-wide variant's 5 x 16 accumulators leave no registers for it: it spilled)
+  constexpr bool GN_OK = BN <= 128;
+  k.prologue_ok = GN_OK ? 1 : 0;
   k.tiles_m = k.N * (k.OH / TH) * (k.OW / 32);
   k.tiles_n = (k.Cout + BN - 1) / BN;
   const int nchunk = k.nk / 9;
@@ -1421,10 +1423,10 @@ int launch_halo(ConvK& k, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  if (k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, true>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
+  if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
   else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
   if (k.splitk > 1) {
     k.patch_tw = 0;                                        // the partial planes are plain [M][Cout]
@@ -1456,7 +1458,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
   // GroupNorm apply fused into the loader: one image per tile only (the 8x8x4 shape has no LDS left for the tables)
   constexpr bool GN_OK = NIMG == 1 && HSLOTS <= 7;
   constexpr bool gnp = GN_OK && GNP;
-  const bool gn_early = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < (WM * WN) / 2;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid % WM, wn = wid / WM;
@@ -1576,10 +1577,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
       if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
       const bool ab_now = gnp && tap == 0 && next_chunk;
       if (ab_now) issue_ab(c + 1);
-      // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it in LDS.  The two waves that share
-      // a SIMD (w, w + NW/2) do it on opposite sides of the tap's MFMA block, so one's VALU work runs under the other's MFMAs.
-      const bool gn_now = gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk;
-      if (gn_now && gn_early) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
+      // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it in LDS next to this tap's MFMAs
+      // (splitting the two waves of a SIMD to opposite sides of the MFMA block measured no gain and cost registers)
+      if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
@@ -1607,7 +1607,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
               acc[a][b] = mfma16t(afr[a], bfr[b], acc[a][b]);
         }
       }
-      if (gn_now && !gn_early) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
       if (ab_now) {                                       // tap 0 with the next chunk's affine table in flight as well
         if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
