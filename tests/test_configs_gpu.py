@@ -94,6 +94,24 @@ def test_config3_seg_1024_one_step(full):
     _check(o, m, img, "seg", 1, dtypes=("bf16",), label="configs[3] 1024x1024 seg / 1 step")
 
 
+def test_config1_full_batch_is_bit_deterministic(full):
+    """The headline workload itself (B=8, 512x512, 20 steps, bf16): graph replays and an eager run agree bit for bit."""
+    _, m = full
+    m.set_num_inference_steps(20)
+    m.set_dtype("bf16")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(48)
+    img = torch.rand(8, 3, 512, 512, generator=g, device=dev)
+    nz = (torch.randn(8, 4, 64, 64, generator=g, device=dev), torch.randn(8, 4, 64, 64, generator=g, device=dev))
+    runs = [m(img, "ir", noise=nz, return_latents=True) for _ in range(3)]
+    m.use_graph = False
+    eager = m(img, "ir", noise=nz, return_latents=True)
+    m.use_graph = True
+    for r in runs[1:] + [eager]:
+        assert all(torch.equal(x, y) for x, y in zip(runs[0], r))
+    assert bool(torch.isfinite(runs[0][0]).all())
+
+
 def test_config4_fifty_steps_fp16_full_size(full):
     """50 DDIM steps in fp16 at full size: finite, in range, bit-identical on a second run (graph replay)."""
     _, m = full

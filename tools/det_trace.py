@@ -1,0 +1,55 @@
+"""Find the first op whose output differs between two eager runs (full size): python tools/det_trace.py [steps] [batch] [dtype]"""
+import os, sys
+os.environ.setdefault("UR_CSCE_STREAM", "0")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch, bench
+from unirestore_amd import ops
+steps, b, dt = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+dev = torch.device("cuda", 0)
+m = bench.build_model(steps, dev, 0, 1, dt)
+m.use_graph = False
+log = []
+def csum(t):
+    t = t.detach().contiguous()
+    iv = t.view(torch.int16) if t.element_size() == 2 else t.view(torch.int32)
+    return torch.stack([iv.long().sum(), (iv.long() * 31 % 1000003).sum()])          # exact integer checksums of the bit patterns
+def wrap(name):
+    f = getattr(ops, name)
+    def g(*a, **k):
+        out = f(*a, **k)
+        ts = out if isinstance(out, (tuple, list)) else (out,)
+        for i, t in enumerate(ts):
+            if torch.is_tensor(t):
+                desc = f"{name}[{i}] {tuple(t.shape)} {t.dtype}"
+                if name == "conv" and len(a) >= 2:
+                    desc += f" k={a[1].k} cin={a[1].cin} cout={a[1].cout} kw={sorted(k2 for k2, v in k.items() if v is not None and v is not False)}"
+                tt = t[..., :k['n_split']] if (name == 'conv' and k.get('yt') is not None) else t      # V columns of a fused QKV go to yt only
+                log[-1].append((desc, csum(tt)))
+                for attr in ("_gn", "_ln"):
+                    st = getattr(t, attr, None)
+                    if st is not None:
+                        log[-1].append((desc + " " + attr, csum(st[0])))
+        return out
+    setattr(ops, name, g)
+for n in ("conv", "attention", "gn_apply", "gn_finalize", "layer_norm", "softmax_rows", "bmm_nt", "scale_channels", "dwconv3x3", "add_noise", "vae_sample", "linear_f32"):
+    wrap(n)
+g = torch.Generator(device=dev).manual_seed(3)
+img = torch.rand(b, 3, 512, 512, generator=g, device=dev)
+nz = (torch.randn(b, 4, 64, 64, generator=g, device=dev), torch.randn(b, 4, 64, 64, generator=g, device=dev))
+log.append([])
+m(img, "ir", noise=nz)          # warm-up: one-time packing / constant K,V
+log.clear()
+for r in range(2):
+    log.append([])
+    m(img, "ir", noise=nz)
+    torch.cuda.synchronize()
+A, B = log
+print("ops per run:", len(A), len(B))
+bad = 0
+for i, ((da, ta), (db, tb)) in enumerate(zip(A, B)):
+    if not torch.equal(ta, tb):
+        print(f"op {i}: {da}  checksums differ")
+        bad += 1
+        if bad >= 6:
+            break
+print("first differing op index printed above" if bad else "all equal")

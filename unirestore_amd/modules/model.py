@@ -181,6 +181,8 @@ class ControlledUNet(nn.Module):
                     edited[idx] = self.csc_editors[idx].run(raw[idx], control[raw[idx].shape[2]])
                     ready[idx] = torch.cuda.Event()
                     ready[idx].record(side)
+            if os.environ.get("UR_DBG_SERIAL_SIDE"):
+                side.synchronize()
             h = u.mid_block.run(h, step=step, ctx=ctx)
         else:
             h = u.mid_block.run(h, step=step, ctx=ctx)
