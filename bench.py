@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0
 from unirestore_amd.init import init_random_  # noqa: E402,F401  (seeded random weights of the reference architecture)
 
 
-def build_model(denoise_steps, device, rank, world, dtype="bf16"):
+def build_model(denoise_steps, device, rank, world, dtype="bf16", use_dist=None):
     import unirestore_amd.modules as M
     kw = dict(frenc=dict(type="CFRM"), cnet=dict(type="scedit", num_inference_steps=denoise_steps),
               tedit=dict(type="TFA", prompt_len=1, task=["ir", "cls", "seg"]))
@@ -42,7 +42,7 @@ def build_model(denoise_steps, device, rank, world, dtype="bf16"):
     model.base_model.null_embeds.copy_(null)
     if rank == 0:
         init_random_(model, 42, device)
-    if world > 1:                            # RCCL: rank 0's weights -> every rank as scatter + all-gather (every xGMI link busy)
+    if (use_dist if use_dist is not None else world > 1):                          # RCCL: rank 0's weights -> every rank as scatter + all-gather (every xGMI link busy)
         import torch.distributed as dist
         from unirestore_amd import dist as urdist
         urdist.broadcast_weights_sharded(model, src=0)
@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit storage / MFMA operand type (headline: bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the weight broadcast / output all-gather even "
+                    "at world size 1 (exercises the N>1 code path - graph capture beside the RCCL watchdog - on a one-GPU box)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -115,11 +117,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
-    model = build_model(args.denoise_steps, dev, rank, world, args.dtype)
+    model = build_model(args.denoise_steps, dev, rank, world, args.dtype, use_dist)
     from unirestore_amd import ops
 
     B, R = args.batch, args.res
@@ -127,27 +132,27 @@ def main():
     gn = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.rand(B, 3, R, R, generator=gi, device=dev)
     noise = (torch.randn(B, 4, R // 8, R // 8, generator=gn, device=dev), torch.randn(B, 4, R // 8, R // 8, generator=gn, device=dev))
-    gathered = torch.empty(world * B, 3, R, R, device=dev) if world > 1 else None
+    gathered = torch.empty(world * B, 3, R, R, device=dev) if use_dist else None
 
     def step():
         out = model(images, "ir", noise=noise)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, out.contiguous())
         return out
 
     for _ in range(max(args.warmup, 1)):          # first call captures the hipGraph
         out = step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -205,21 +210,22 @@ def main():
                               "share_of_forward": round(dom["ms"] / sum(v["ms"] for v in rep.values()), 3)}
         # HBM bytes of the most frequent launch of the conv family (conv3x3 320->320 @64x64, B=8), from separate rocprofv3 --pmc
         # passes (FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE), committed file; null for other families
-        for cand in ("r2_pmc_dominant.json", "r1_pmc_halo_conv.json"):
+        for cand in ("r2_pmc_dominant.json", "r2_pmc_halo_conv.json"):
             pmc = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
-                if pj.get("family", "conv3x3_igemm") == dom_name:
+                if pj.get("family") == dom_name:
                     result["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
+                    result["roofline"]["traffic_algorithmic"] = pj["algorithmic_bytes_per_launch"]
                     result["roofline"]["traffic_note"] = pj["note"]
-                break
+                    break
         result["families"] = fam
         result["profiled_forward_ms"] = round(sum(v["ms"] for v in rep.values()), 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"], result["parity_vs_oracle"] = cpu_baseline(model, args.denoise_steps)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
