@@ -88,3 +88,39 @@ def test_spade_checkpoint_slices(tmp_path):
             assert torch.equal(a[k], b[k]), k
             n += 1
     assert n > 100 and not hasattr(dst.base_model, "csc_editors")
+
+
+def test_hf_unet_into_spade_model_and_deprecated_vae_names(tmp_path):
+    """ An HF UNet file has no SPADE keys: a control_type='spade' model must still take it (only '.spade.' keys may
+    be missing); SD-2.x VAE exports with the pre-0.18 attention names (query / key / value / proj_attn) load after the rename."""
+    from safetensors.torch import save_file
+    from unirestore_amd import checkpoint as ck
+    from unirestore_amd.modules import DiffUIE
+    kw = model_kwargs(1)
+    torch.manual_seed(2)
+    plain = DiffUIE(**kw, **TINY); randomise_(plain, 5)
+    os.makedirs(tmp_path / "hf" / "unet"); os.makedirs(tmp_path / "hf" / "vae")
+    save_file({k: v.contiguous() for k, v in plain.base_model.unet.state_dict().items()}, str(tmp_path / "hf" / "unet" / "diffusion_pytorch_model.safetensors"))
+    old = {}
+    for k, v in plain.ae.vae.state_dict().items():
+        if k.startswith(("encoder.fr_blocks.", "decoder.task_")):
+            continue
+        for new, dep in ((".to_q.", ".query."), (".to_k.", ".key."), (".to_v.", ".value."), (".to_out.0.", ".proj_attn.")):
+            if ".attentions." in k and new in k:
+                k = k.replace(new, dep)
+        old[k] = v.contiguous()
+    assert any(".proj_attn." in k for k in old)
+    save_file(old, str(tmp_path / "hf" / "vae" / "diffusion_pytorch_model.safetensors"))
+    kw2 = model_kwargs(1); kw2["cnet"]["type"] = "spade"
+    dst = DiffUIE(**kw2, **TINY)
+    rep = ck.load_hf_weights(dst, str(tmp_path / "hf"))
+    assert rep["unet"] > 100 and rep["vae"] > 100
+    a, b = plain.base_model.unet.state_dict(), dst.base_model.unet.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a) and any(".spade." in k for k in b)
+    va, vb = plain.ae.vae.state_dict(), dst.ae.vae.state_dict()
+    assert all(torch.equal(va[k], vb[k]) for k in va if ".attentions." in k)
+    # a UNet file that lacks a NON-spade key is still rejected
+    bad = {k: v.contiguous() for k, v in plain.base_model.unet.state_dict().items() if k != "conv_in.bias"}
+    save_file(bad, str(tmp_path / "hf" / "unet" / "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(RuntimeError):
+        ck.load_hf_weights(dst, str(tmp_path / "hf"), components=("unet",))

@@ -303,3 +303,42 @@ def test_training_side_forwards_diffuse_and_predict_z0(M, dtype):
     assert e < TOL[dtype]["eps"]
     rnd, _, tt = p.diffuse(lat)                                # random training timesteps come from train_timesteps
     assert set(tt.tolist()) <= {249, 499, 749, 999} and rnd.shape == lat.shape
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_training_step_forward_halves(M, dtype):
+    """the forward halves of LitUniFIE.training_step (engine_unifie.py:135-191) - CFRM feature-MSE taps,
+    control-stage z0 prediction, TFA decode - against the same composition of oracle calls."""
+    import torch.nn.functional as F
+    from unirestore_amd import runner
+    o, p = _pair(M, 10, dtype=dtype)
+    lit = runner.LitUniFIE(model_kwargs(2), model=p)
+    g = torch.Generator().manual_seed(26)
+    hq = torch.rand(2, 3, 64, 64, generator=g)
+    lq = (hq + 0.1 * torch.randn(hq.shape, generator=g)).clamp(0, 1)
+    nz = torch.randn(2, 4, 8, 8, generator=g)
+    # product (explicit noise through the model API so that both sides see the same posterior sample)
+    ph0, ph0m = p.ae.encode(hq, enable_fr=False, noise=nz)
+    pl0, pl0m = p.ae.encode(lq, enable_fr=True, noise=nz)
+    with torch.no_grad():
+        oh0, oh0m = o.ae.encode(hq, enable_fr=False, noise=nz)
+        ol0, ol0m = o.ae.encode(lq, enable_fr=True, noise=nz)
+    pls, ols = lit.fr_loss_fn(ph0, ph0m, pl0, pl0m), lit.fr_loss_fn(oh0, oh0m, ol0, ol0m)
+    for k in ols:
+        assert abs(float(pls[k]) - float(ols[k])) <= 3 * TOL[dtype]["res"] * abs(float(ols[k])) + 1e-9, (k, float(pls[k]), float(ols[k]))
+    ref_frenc = 0.1 * F.mse_loss(ol0m[0], oh0m[0]) + 0.1 * F.mse_loss(ol0m[1], oh0m[1]) + 0.01 * F.mse_loss(ol0m[2], oh0m[2])
+    assert abs(float(ols["loss_frenc"]) - float(ref_frenc)) < 1e-6 * float(ref_frenc) + 1e-12
+    ts, eps_t = torch.tensor([499, 999]), torch.randn(2, 4, 8, 8, generator=g)
+    pz = lit.cn_training_fwd(oh0, ol0, ts, eps_t)
+    with torch.no_grad():
+        ozt, _, _ = o.diffuse(oh0, ts, eps_t)
+        oz = o.predict_z0(ozt, ol0, ts)
+    assert rel_l2(pz.cpu(), oz) < TOL[dtype]["eps"]
+    assert abs(float(lit.cn_loss_fn(pz, oh0)) - float(F.mse_loss(oz, oh0))) < 5e-2 * float(F.mse_loss(oz, oh0))
+    pim = lit.te_training_fwd(oz, ol0m, "cls")
+    with torch.no_grad():
+        oim = o.ae.decode(oz, ol0m, "cls")
+    assert rel_l2(pim.cpu(), oim) < TOL[dtype]["img"]
+    lit.noise_seed = 3                                      # the wrapper itself: reproducible, shapes as the reference's tuple
+    a, b = lit.fr_training_fwd(hq, lq), lit.fr_training_fwd(hq, lq)
+    assert len(a) == 4 and len(a[1]) == 3 and all(torch.equal(x, y) for x, y in zip(a[1] + a[3], b[1] + b[3]))

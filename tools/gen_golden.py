@@ -53,6 +53,9 @@ def _randomise(m, gen):
 
 
 def _save(name, module, inputs, outputs):
+    if os.path.exists(os.path.join(OUT, name + ".npz")) and "--force" not in sys.argv:
+        print(name, "exists (kept; --force regenerates)")
+        return
     d = {f"w::{k}": v.detach().numpy() for k, v in module.state_dict().items()}
     d.update({f"in::{k}": v.numpy() for k, v in inputs.items()})
     d.update({f"out::{k}": v.detach().numpy() for k, v in outputs.items() if v is not None})
@@ -94,6 +97,14 @@ def main():
     m = spade.SPADE(64, 32).eval()
     x, seg = rn(2, 64, 16, 16), rn(2, 32, 8, 8)
     _save("spade_0", m, dict(x=x, segmap=seg), dict(y=m(x, seg)))
+
+    # production-width SC-Tuner ((C, Cc, h, w) = (320, 256, 8, 8)); its own generator so that the vectors above
+    # do not move when cases are appended
+    g2 = torch.Generator().manual_seed(20250615)
+    torch.manual_seed(102)
+    m = scedit.CSCEAdapter(320, 320, 256).eval()
+    x, cond = torch.randn(2, 320, 8, 8, generator=g2), torch.randn(2, 256, 8, 8, generator=g2)
+    _save("csce_2", m, dict(x=x, condition=cond), dict(y=m(x, cond)))
 
 
 if __name__ == "__main__":

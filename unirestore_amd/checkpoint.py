@@ -88,6 +88,25 @@ def read_tensors(path: str) -> Dict[str, torch.Tensor]:
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
+# SD-2.x VAE exports made before diffusers 0.18 name the mid-block attention projections query / key / value / proj_attn
+# (diffusers renames them on load); newer ones use to_q / to_k / to_v / to_out.0
+_DEPRECATED_ATTN = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
+
+
+def remap_deprecated_vae_attention(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in sd.items():
+        if ".attentions." in k:
+            for old, new in _DEPRECATED_ATTN.items():
+                if old in k:
+                    k = k.replace(old, new)
+                    if v.dim() == 4 and v.shape[-2:] == (1, 1):      # very old exports hold them as 1x1 convs
+                        v = v[:, :, 0, 0]
+                    break
+        out[k] = v
+    return out
+
+
 ADAPTER_KEYS = ("encoder.fr_blocks.", "decoder.task_prompts.", "decoder.task_editors.")
 
 
@@ -97,10 +116,15 @@ def load_hf_weights(model, root: str, components: Iterable[str] = ("unet", "vae"
     report = {}
     if "unet" in components and getattr(model, "control_type", None):
         sd = read_tensors(_find_weights(os.path.join(root, "unet")))
-        model.base_model.unet.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+        # control_type "spade" grafts SPADE modules onto the UNet's resnets BEFORE the weights arrive (the reference calls
+        # from_pretrained first, base_model.py:32-37): those - and only those - may be absent from the HF file
+        res = model.base_model.unet.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
+        bad = [k for k in res.missing_keys if ".spade." not in k]
+        if bad or res.unexpected_keys:
+            raise RuntimeError(f"UNet weights do not match: missing {bad[:5]} unexpected {list(res.unexpected_keys)[:5]}")
         report["unet"] = len(sd)
     if "vae" in components:
-        sd = read_tensors(_find_weights(os.path.join(root, "vae")))
+        sd = remap_deprecated_vae_attention(read_tensors(_find_weights(os.path.join(root, "vae"))))
         res = model.ae.vae.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
         bad = [k for k in res.missing_keys if not k.startswith(ADAPTER_KEYS)]
         if bad or res.unexpected_keys:

@@ -94,6 +94,45 @@ class LitUniFIE:
             self.totals["images"] += n
         return preds
 
+    # ---- the training step's FORWARD halves (engine_unifie.py:135-191), values only: the HIP path has no autograd ------------
+    @torch.no_grad()
+    def fr_training_fwd(self, hq, lq):
+        """AE encoder (+CFRM on the degraded input): (h0, h0_mids, l0, l0_mids) - engine_unifie.py:135-148."""
+        h0, h0_mids = self.model.ae.encode(hq, enable_fr=False, noise=self._noise(hq))
+        l0, l0_mids = self.model.ae.encode(lq, enable_fr=bool(self.model_kwargs.get("frenc")), noise=self._noise(lq))
+        return h0, h0_mids, l0, l0_mids
+
+    @staticmethod
+    def fr_loss_fn(h0, h0_mids, l0, l0_mids):
+        """Feature-MSE taps of the CFRM stage: 0.1 * L1 + 0.1 * L2 + 0.01 * L3 (+ the latent MSE it logs) - :150-168."""
+        mse = lambda a, b: torch.mean((a.float() - b.float()) ** 2)
+        layers = [mse(a, b) for a, b in zip(l0_mids, h0_mids)]
+        return dict(loss_layer1=layers[0], loss_layer2=layers[1], loss_layer3=layers[2], loss_enc=mse(l0, h0),
+                    loss_frenc=0.1 * layers[0] + 0.1 * layers[1] + 0.01 * layers[2])
+
+    @torch.no_grad()
+    def cn_training_fwd(self, h0, l0, timesteps=None, noise=None):
+        """Controller + SC-Tuner + UNet: diffuse the clean latent, predict z0 under the degraded latent's control - :170-178."""
+        zt, _, ts = self.model.diffuse(h0, timesteps, noise)
+        return self.model.predict_z0(zt, conditions=l0, timesteps=ts)
+
+    @staticmethod
+    def cn_loss_fn(pred_z0, h0):
+        return torch.mean((pred_z0.float() - h0.float().to(pred_z0.device)) ** 2)
+
+    @torch.no_grad()
+    def te_training_fwd(self, pred_z0, l0_mids, task):
+        """AE decoder + TFA on the predicted latent - :186-191."""
+        return self.model.ae.decode(pred_z0, l0_mids, task)
+
+    noise_seed = None          # set to an int to make the VAE's posterior sampling reproducible (tests)
+
+    def _noise(self, img):
+        if self.noise_seed is None:
+            return None
+        g = torch.Generator().manual_seed(self.noise_seed + int(img.shape[-1]))
+        return torch.randn(img.shape[0], self.model.ae.vae.latent_channels, img.shape[-2] // 8, img.shape[-1] // 8, generator=g)
+
     def metrics(self) -> dict:
         n = max(self.totals["images"], 1)
         return {"val_lq/psnr": self.totals["psnr"] / n, "val_lq/ssim": self.totals["ssim"] / n, "images": self.totals["images"]}
