@@ -9,6 +9,7 @@ dev = torch.device("cuda", 0)
 m = bench.build_model(steps, dev, 0, 1, dt)
 m.use_graph = False
 log = []
+KEEP = os.environ.get("DET_KEEP") == "1"      # keep the tensors too (few steps only): prints WHERE two runs differ
 def csum(t):
     t = t.detach().contiguous()
     iv = t.view(torch.int16) if t.element_size() == 2 else t.view(torch.int32)
@@ -24,11 +25,11 @@ def wrap(name):
                 if name == "conv" and len(a) >= 2:
                     desc += f" k={a[1].k} cin={a[1].cin} cout={a[1].cout} kw={sorted(k2 for k2, v in k.items() if v is not None and v is not False)}"
                 tt = t[..., :k['n_split']] if (name == 'conv' and k.get('yt') is not None) else t      # V columns of a fused QKV go to yt only
-                log[-1].append((desc, csum(tt)))
+                log[-1].append((desc, csum(tt), tt.detach().clone() if KEEP else None))
                 for attr in ("_gn", "_ln"):
                     st = getattr(t, attr, None)
                     if st is not None:
-                        log[-1].append((desc + " " + attr, csum(st[0])))
+                        log[-1].append((desc + " " + attr, csum(st[0]), None))
         return out
     setattr(ops, name, g)
 for n in ("conv", "attention", "gn_apply", "gn_finalize", "layer_norm", "softmax_rows", "bmm_nt", "scale_channels", "dwconv3x3", "add_noise", "vae_sample", "linear_f32"):
@@ -46,9 +47,15 @@ for r in range(2):
 A, B = log
 print("ops per run:", len(A), len(B))
 bad = 0
-for i, ((da, ta), (db, tb)) in enumerate(zip(A, B)):
+for i, ((da, ta, xa), (db, tb, xb)) in enumerate(zip(A, B)):
     if not torch.equal(ta, tb):
         print(f"op {i}: {da}  checksums differ")
+        if xa is not None:
+            d = (xa.float() - xb.float()).reshape(-1, xa.shape[-1])
+            nz = d != 0
+            rows = nz.any(1).nonzero().flatten(); cols = nz.any(0).nonzero().flatten()
+            print(f"     {int(nz.sum())} of {nz.numel()} elements differ; rows {int(rows.min())}..{int(rows.max())} ({rows.numel()} rows), cols {int(cols.min())}..{int(cols.max())} ({cols.numel()} cols), "
+                  f"max|diff| {float(d.abs().max()):.3e}; first rows {rows[:12].tolist()}")
         bad += 1
         if bad >= 6:
             break

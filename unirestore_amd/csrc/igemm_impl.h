@@ -999,6 +999,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
   };
 
   // ---- ring: tile t lives in stage t % NST; up to NST-1 tiles are in flight ahead of the MFMAs -----------------------
+  // The wait in front of every barrier also retires this wave's LDS READS (lgkmcnt(0)): the tile issued right after the barrier
+  // lands in the stage that was read in THIS iteration, and hipcc otherwise leaves the last fragment reads outstanding across
+  // the barrier (it sinks the last MFMAs below it) - under LDS contention from a co-resident kernel the DMA then overwrote
+  // fragments that had not been read yet (found in round 2 as run-to-run differences with the SC-Tuner side stream on).
   const int ntile = (p.dbg & 8) ? 0 : kt_end - kt_begin;
   if (ntile > 0) {
     int issued = 0;
@@ -1006,8 +1010,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
     for (int s = 0; s < NST - 1; ++s)
       if (issued < ntile) { issue_tile(s); ++issued; }
     // wait for tile 0
-    if (issued >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST - 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (issued >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD * (NST - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int cs = 0, is = (NST - 1) % NST;
     for (int t = 0; t < ntile; ++t) {
@@ -1016,8 +1020,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
       if (!(p.dbg & 2)) compute(cs);
       cs = (cs + 1 == NST) ? 0 : cs + 1;
       // tile t+1 must have landed before anyone reads it: all but the newest (NST-2) tiles' DMAs retired
-      if (issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST - 2)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD * (NST - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
@@ -1089,8 +1093,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (issued < ntile) { issue_tile(s); ++issued; }
-  if (NST >= 3 && issued >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (NST >= 3 && issued >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int cs = 0, is = (NST - 1) % NST;
   for (int t = 0; t < ntile; ++t) {
@@ -1118,8 +1122,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
           acc[a][b] = mfma16t(afr[a], bfr[b], acc[a][b]);
     }
     cs = (cs + 1 == NST) ? 0 : cs + 1;
-    if (NST >= 3 && issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NST >= 3 && issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, DIRECT, PAIRC>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
@@ -1387,7 +1391,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
       else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
       else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (gnp) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the in-place GroupNorm writes are published by the barrier
+      // lgkmcnt(0): (1) this wave's fragment reads of the ring slot / halo buffer that the NEXT tap's DMA overwrites are retired
+      // before anyone passes the barrier (hipcc leaves the last reads outstanding across it otherwise - see igemm_glds_kernel);
+      // (2) the in-place GroupNorm writes are published by the barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
@@ -1614,7 +1621,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
       else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
       else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (gnp) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the in-place GroupNorm writes are published by the barrier
+      // lgkmcnt(0): (1) this wave's fragment reads of the ring slot / halo buffer that the NEXT tap's DMA overwrites are retired
+      // before anyone passes the barrier (hipcc leaves the last reads outstanding across it otherwise - see igemm_glds_kernel);
+      // (2) the in-place GroupNorm writes are published by the barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }

@@ -178,7 +178,14 @@ class ControlledUNet(nn.Module):
             with torch.cuda.stream(side):
                 side.wait_event(fork)
                 for idx in reversed(range(len(raw))):
-                    edited[idx] = self.csc_editors[idx].run(raw[idx], control[raw[idx].shape[2]])
+                    cond = control[raw[idx].shape[2]]
+                    if os.environ.get("UR_DBG_RECORD_STREAM"):
+                        raw[idx].record_stream(side); cond.record_stream(side)
+                    edited[idx] = self.csc_editors[idx].run(raw[idx], cond)
+                    if os.environ.get("UR_DBG_RECORD_STREAM"):
+                        edited[idx].record_stream(main)
+                        if ops.gn_of(edited[idx]) is not None:
+                            ops.gn_of(edited[idx])[0].record_stream(main)
                     ready[idx] = torch.cuda.Event()
                     ready[idx].record(side)
             if os.environ.get("UR_DBG_SERIAL_SIDE"):

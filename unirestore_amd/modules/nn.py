@@ -19,10 +19,12 @@ from .. import ops
 from ..ops import UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_SILU
 
 DEV = "cuda"
-# SC-Tuner adapters as a parallel branch of the graph (side stream).  OFF by default since round 2: with the branch on, two
-# replays of a full-size forward differed (zt max |diff| ~0.09 at B=8) although every kernel is atomics-free and
-# tools/race_probe.py shows the GEMMs bit-stable beside other kernels - an unresolved cross-stream hazard in the model graph,
-# not worth the measured 1.3 % (314.8 vs 319.0 ms per batch).  tools/det_check.py / det_trace.py reproduce it with =1.
+# SC-Tuner adapters as a parallel branch of the graph (side stream).  OFF by default since round 2.  With the branch on, replays
+# of a full-size forward differed (zt max |diff| ~0.09 at B=8): tools/det_trace.py traced it to the LDS-DMA GEMM kernels - a
+# write-after-read race on the K ring (the DMA of the next tile overwrote fragments whose reads were still outstanding across
+# the barrier) that only fired under LDS contention from a co-resident kernel.  Fixed in the kernels (lgkmcnt(0) in front of the
+# ring barriers, igemm_impl.h); graph replays are bit-identical with the branch on or off.  It stays off because it no longer
+# pays (314.9 vs 315.6 ms per batch) and eager (non-graph) runs with it on still show run-to-run differences at B=3.
 SIDE_STREAM = os.environ.get("UR_CSCE_STREAM", "0") == "1"
 side_stream = ops.side_stream
 
