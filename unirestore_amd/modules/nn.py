@@ -175,14 +175,17 @@ FUSE_GN = os.environ.get("UR_FUSE_GN", "1") == "1"       # GroupNorm apply + SiL
 # Measured (tools/ab_micro.py, MI355X): the in-LDS pass costs the halo conv ~15 us per launch on top of its MFMA time (the two
 # waves of a SIMD meet at a barrier every tap, so little of the VALU work hides), which beats the separate apply pass (HBM read
 # + write of the whole activation) only on the VAE's large maps: 128 ch @ 512x512 245 vs 253 us, 320 ch @ 64x64 85 vs 79.5 us.
+# The in-loader pass is repeated by every output-channel tile of the same pixels (and by neighbouring patches for the halo), so
+# it only pays where the conv has one or two channel tiles: Cout <= 256 (VAE levels, Controller), not the UNet's 320-1280.
 FUSE_GN_MIN_PIXELS = int(os.environ.get("UR_FUSE_GN_MIN_PIXELS", str(256 * 256)))
+FUSE_GN_MAX_COUT = int(os.environ.get("UR_FUSE_GN_MAX_COUT", "256"))
 
 
 def gn_silu_conv(norm: "GroupNorm", x, pc, x2=None, **kw):
     """conv(SiLU(GroupNorm(x | x2))): statistics -> per-(image, channel) affine, then either the conv applies it while it
     loads its input patch (no normalised tensor in HBM) or a separate apply pass runs first."""
     ab = norm.coeffs(x, x2=x2)
-    if FUSE_GN and x.shape[1] * x.shape[2] >= FUSE_GN_MIN_PIXELS and \
+    if FUSE_GN and x.shape[1] * x.shape[2] >= FUSE_GN_MIN_PIXELS and pc.cout_out <= FUSE_GN_MAX_COUT and \
             ops.conv_plan(x, pc, x2=x2, gn=kw.get("gn", False), gn_ab=True, residual=kw.get("residual") is not None).prologue_ok:
         return ops.conv(x, pc, x2=x2, gn_ab=ab, gn_silu=True, **kw)
     return ops.conv(ops.gn_apply(x, ab, silu=True, x2=x2), pc, **kw)
