@@ -72,6 +72,9 @@ static inline int himg_16x16(void* kp, hipStream_t s) { return static_cast<ConvK
 int himg_8x8x4_bf16(void* kp, hipStream_t s);
 int himg_8x8x4_f16(void* kp, hipStream_t s);
 static inline int himg_8x8x4(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? himg_8x8x4_f16(kp, s) : himg_8x8x4_bf16(kp, s); }
+#ifdef UR_AB_VARIANTS
+int g1_ab_bf16(void* kp, hipStream_t s, int id);
+#endif
 }  // namespace urk
 
 namespace {
@@ -124,9 +127,16 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   static const bool g1dma = getenv("UR_IGEMM_NOG1DMA") == nullptr;
   const bool g1 = g1dma && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.pad_t == 0 && k.pad_l == 0 && k.OH == k.H && k.OW == k.W &&
                   (long long)k.M * k.ldx + k.Ktot < (1ll << 31);
+#ifdef UR_AB_VARIANTS
+  if (const char* ab = getenv("UR_AB_ID")) if (g1 && !pair && !k.f16 && atoi(ab) >= 0) return urk::g1_ab_bf16(&k, s, atoi(ab));
+#endif
   auto nosplit = [&](int bm, int bn) { return (long long)((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn) * k.nbatch >= 200 || k.nk < 8 || !k.ws; };
   if (!no_t64 && k.KH == 1 && !pair && k.Cout > 64) {
     // too few 128 x 128 tiles to fill 256 CUs and K too short for split-K to pay for its reduce pass: 64 x 64 tiles
+    // (>= 128 such tiles run faster unsplit up to K = 3072 than split with a reduce pass: 512 x 1280 x 1280 11.3 vs 14.6 us,
+    //  2048 x 1280 x 2560 29 vs 34 us - tools/ab_gemm_sweep.py)
+    const long long blocks64 = (long long)((k.M + 63) / 64) * ((k.Cout + 63) / 64) * k.nbatch;
+    if (blocks128 < 200 && g1 && ((blocks64 >= 128 && k.nk <= 24) || (blocks64 >= 256 && k.nk <= 48))) return urk::g1_64x64(&k, s);
     if (blocks128 < 200 && k.nk <= 24) return g1 && nosplit(64, 64) ? urk::g1_64x64(&k, s) : urk::v1_64x64(&k, s);
     // 1 < tiles/CU < 2 at 128 x 128: halve the N tile so every CU gets the same work
     if (use_v1 && blocks128 > 256 && blocks128 < 400 && k.Cout % 128 == 0) return g1 && nosplit(128, 64) ? urk::g1_128x64(&k, s) : urk::v1_128x64(&k, s);
@@ -154,6 +164,8 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
     if (t128 >= 200) return urk::g1_128x128(&k, s);
   }
   if (big_tiles >= 160) {
+    // pure GEMMs onto 320/960-wide outputs: two 128 x 160 workgroups per CU beat one 256 x 160 (32768 x 320 x 1280: 41 vs 44.5 us)
+    if (n160 && g1 && !no_fill) return urk::g1_128x160(&k, s);
     if (n160) return urk::v2_256x160(&k, s);
     return urk::v2_256x128(&k, s);
   }
