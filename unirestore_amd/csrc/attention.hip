@@ -188,14 +188,22 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[f][e] *= alpha;
     }
-    const float mc = m_run * c;
-    float psum = 0.f;
+    // the scale-and-shift and the row sum run as packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32): the softmax VALU work, not
+    // the MFMAs, bounds this kernel at d = 64 (32 quarter-rate exp2 + ~100 full-rate ops against 16 MFMAs per tile and wave)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 c2 = {c, c}, mc2 = {-m_run * c, -m_run * c};
+    f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], c, -mc));
-      psum += s[i];
+    for (int i = 0; i < 32; i += 2) {
+      f32x2 v = {s[i], s[i + 1]};
+      v = __builtin_elementwise_fma(v, c2, mc2);
+      v.x = __builtin_amdgcn_exp2f(v.x);
+      v.y = __builtin_amdgcn_exp2f(v.y);
+      ps2 += v;
+      s[i] = v.x;
+      s[i + 1] = v.y;
     }
-    l_run += psum;
+    l_run += ps2.x + ps2.y;
 
     // ---- O^T += V^T P^T : 4 k-steps of 16 keys; P^T fragment = 8 consecutive accumulator registers ----
 #pragma unroll
