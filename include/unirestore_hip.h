@@ -165,9 +165,12 @@ int ur_softmax_rows_f32(const float* s, void* p, long long rows, int cols, int l
 
 /* ---- attention (flash-style, bf16 MFMA, fp32 softmax) ------------------------------------------
  * o[b,t,h*D+d] = softmax_k(q.k * scale) v.  q:[B][Tq][ldq], k:[B][Tk][ldk] (head h at column h*D),
- * vt:[B][H*D][ldvt] (V transposed: row = channel, column = key index), o:[B][Tq][ldo].  D in {64,128}.
+ * vt:[B][H*D][ldvt] (V transposed: row = channel, column = key index), o:[B][Tq][ldo].  D in {64,128,512}
+ * (512: the single 512-wide head of the VAE mid-block attention, split over keys for q.k and over channels for p.v
+ *  inside one workgroup - no Tq x Tk matrix is materialised at any D).
  * Replaces: F.scaled_dot_product_attention via diffusers AttnProcessor2_0 (UNet self/cross attention,
- *   Controller AttnDownBlock2D / UNetMidBlock2D attention).
+ *   Controller AttnDownBlock2D / UNetMidBlock2D attention) and the VAE mid-block AttentionBlock
+ *   (/root/reference/src/modules/diffuie/autoencoder.py:37-45 calls it through vae.encoder/decoder.mid_block).
  */
 int ur_attention_fwd(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk,
                      int D, int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k,

@@ -166,7 +166,8 @@ def test_softmax_rows(ops):
 
 
 @pytest.mark.parametrize("b,heads,d,tq,tk", [(2, 2, 64, 256, 256), (1, 5, 64, 1024, 77), (2, 4, 128, 64, 64), (1, 1, 64, 100, 200),
-                                              (2, 4, 128, 256, 77)])
+                                              (2, 4, 128, 256, 77), (2, 1, 512, 256, 256), (1, 1, 512, 100, 200), (1, 2, 512, 64, 77),
+                                              (1, 1, 512, 1024, 1024)])
 def test_attention(ops, b, heads, d, tq, tk):
     g = _gen(tq + tk + d)
     c = heads * d
@@ -180,15 +181,16 @@ def test_attention(ops, b, heads, d, tq, tk):
     assert rel_l2(o.float().cpu(), ref) < 2 * TOL_BF16   # P is rounded to 16 bits before PV (as SDPA's 16-bit path does)
 
 
-def test_attention_softmax_spike(ops):
+@pytest.mark.parametrize("d", [64, 512])
+def test_attention_softmax_spike(ops, d):
     """Force a large running-max jump mid-stream (online-softmax rescale path)."""
     g = _gen(9)
-    b, heads, d, t = 1, 1, 64, 256
+    b, heads, t = 1, 1, 256
     q = _rb(torch.randn(b, t, d, generator=g)); k = _rb(torch.randn(b, t, d, generator=g)); v = _rb(torch.randn(b, t, d, generator=g))
     k[0, 200] = q[0, 5] * 8
-    ref = torch.softmax(q @ k.transpose(-1, -2) / 8, -1) @ v
+    ref = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), -1) @ v
     vt = v.transpose(1, 2).contiguous().to(DT)
-    o = ops.attention(q.to(DT).cuda(), k.to(DT).cuda(), vt.cuda(), 1, d, t, t, 0.125, ldq=d, ldk=d,
+    o = ops.attention(q.to(DT).cuda(), k.to(DT).cuda(), vt.cuda(), 1, d, t, t, 1 / math.sqrt(d), ldq=d, ldk=d,
                       bs_q=t * d, bs_k=t * d, bs_vt=d * t, batch=1)
     assert rel_l2(o.float().cpu(), ref) < 2 * TOL_BF16
 

@@ -10,18 +10,12 @@
 //   * 4 waves x 32 queries per workgroup share 64-key K / V^T tiles staged through registers into
 //     XOR-swizzled LDS (2 stages, one barrier per tile); swizzles verified by tools/lds_conflicts.py.
 #include "common.h"
+#include "attention_params.h"
 
 // 128 B of zeros: source of out-of-range 16-byte pieces for the LDS-DMA loader
 static __device__ uint4 g_attn_zero_page[8];
 
 namespace {
-
-struct AttnP {
-  const uint16_t* q; const uint16_t* k; const uint16_t* vt; uint16_t* o;
-  int B, H, Tq, Tk, ldq, ldk, ldvt, ldo;
-  long long bs_q, bs_k, bs_vt, bs_o;
-  float scale_log2e;
-};
 
 __device__ __forceinline__ int swap23(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
@@ -257,6 +251,8 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
 #endif
 int ur_attn_launch_bf16(const void* pp, int D, hipStream_t s);
 int ur_attn_launch_f16(const void* pp, int D, hipStream_t s);
+int ur_attn512_launch_bf16(const void* pp, hipStream_t s);
+int ur_attn512_launch_f16(const void* pp, hipStream_t s);
 
 int UR_ATTN_LAUNCH(const void* pp, int D, hipStream_t s) {
   const AttnP& p = *static_cast<const AttnP*>(pp);
@@ -282,7 +278,7 @@ extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, vo
                                 int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k, long long bs_vt,
                                 long long bs_o, float scale, int dtype, ur_stream_t stream) {
   UR_REQUIRE(q && k && vt && o, "null pointer");
-  UR_REQUIRE(D == 64 || D == 128, "head dim must be 64 or 128 (use the GEMM path otherwise)");
+  UR_REQUIRE(D == 64 || D == 128 || D == 512, "head dim must be 64, 128 or 512 (use the GEMM path otherwise)");
   UR_REQUIRE_DT(dtype);
   UR_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "empty problem");
   UR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Tk, "leading dims");
@@ -295,6 +291,7 @@ extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, vo
   const double flops = 4.0 * B * H * (double)Tq * Tk * D;
   const double bytes = 2.0 * B * H * ((double)Tq * D * 2 + (double)Tk * D * 2);
   ur::ProfScope prof("attention", flops, bytes, s);
+  if (D == 512) return dtype == UR_DT_F16 ? ur_attn512_launch_f16(&p, s) : ur_attn512_launch_bf16(&p, s);     // attention512.hip
   return dtype == UR_DT_F16 ? ur_attn_launch_f16(&p, D, s) : ur_attn_launch_bf16(&p, D, s);
 }
 #endif

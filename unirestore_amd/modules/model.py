@@ -179,17 +179,9 @@ class ControlledUNet(nn.Module):
                 side.wait_event(fork)
                 for idx in reversed(range(len(raw))):
                     cond = control[raw[idx].shape[2]]
-                    if os.environ.get("UR_DBG_RECORD_STREAM"):
-                        raw[idx].record_stream(side); cond.record_stream(side)
                     edited[idx] = self.csc_editors[idx].run(raw[idx], cond)
-                    if os.environ.get("UR_DBG_RECORD_STREAM"):
-                        edited[idx].record_stream(main)
-                        if ops.gn_of(edited[idx]) is not None:
-                            ops.gn_of(edited[idx])[0].record_stream(main)
                     ready[idx] = torch.cuda.Event()
                     ready[idx].record(side)
-            if os.environ.get("UR_DBG_SERIAL_SIDE"):
-                side.synchronize()
             h = u.mid_block.run(h, step=step, ctx=ctx)
         else:
             h = u.mid_block.run(h, step=step, ctx=ctx)

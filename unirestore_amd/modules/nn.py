@@ -242,6 +242,9 @@ def _fused_ln(mod, key, names, norm, pair=False):
     return mod.__dict__[ck]
 
 
+NO_FLASH512 = os.environ.get("UR_NO_FLASH512", "0") == "1"     # A/B switch: chunked GEMM form for the d = 512 VAE attention
+
+
 def self_attention(mod, h, heads, residual, gn_kw={}, ln=None, rows=False):
     """h: [B,T,C] bf16.  One fused QKV GEMM (V written transposed), flash attention, output projection with the
     residual in its epilogue.  ln=(norm, row_stats): h is the RAW residual stream and LayerNorm is folded into the QKV
@@ -255,7 +258,7 @@ def self_attention(mod, h, heads, residual, gn_kw={}, ln=None, rows=False):
         qk = ops.linear(h, _fused_ln(mod, "qkv", ("to_q", "to_k", "to_v"), ln[0]), ln_stats=ln[1], yt=vt, n_split=2 * c, t_rows=t)
     else:
         qk = ops.linear(h, _fused_qkv(mod, ("to_q", "to_k", "to_v")), yt=vt, n_split=2 * c, t_rows=t)   # [B,T,3C] (V cols unused)
-    if d in (64, 128):
+    if d in (64, 128) or (d == 512 and not NO_FLASH512):
         o = ops.attention(qk, qk[:, :, c:], vt, heads, d, t, t, 1.0 / math.sqrt(d), ldq=3 * c, ldk=3 * c,
                           bs_q=t * 3 * c, bs_k=t * 3 * c, bs_vt=c * ldvt, batch=b)
     else:
