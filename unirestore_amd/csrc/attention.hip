@@ -23,6 +23,9 @@ template <int D, bool F16>
 #ifndef UR_ATTN_WAVES
 #define UR_ATTN_WAVES 3
 #endif
+#ifndef UR_ATTN_ABL
+#define UR_ATTN_ABL 0      // timing-only ablations (profiles/r2_c_pmc_attention.txt): 1 = no exp2, 2 = one P.V MFMA per tile, 3 = no row maximum
+#endif
 __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_kernel(const AttnP p) {
   constexpr int KROW = D * 2;                 // bytes per K row in LDS
   constexpr int KSLOTS = KROW / 16;           // 16-B slots per K row (8 or 16)
@@ -166,8 +169,10 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
     }
     // online softmax in the exp2 domain on RAW scores: p = exp2(c*s - c*m), c = scale*log2(e) folded into one FMA.
     float mx = s[0];
+#if UR_ATTN_ABL != 3
 #pragma unroll
     for (int i = 1; i < 32; ++i) mx = fmaxf(mx, s[i]);
+#endif
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float c = p.scale_log2e;
     // deferred rescale: while no row's maximum grew by more than 2^8 (in the exp2 domain) keep the old reference
@@ -182,22 +187,18 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[f][e] *= alpha;
     }
-    // the scale-and-shift and the row sum run as packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32): the softmax VALU work, not
-    // the MFMAs, bounds this kernel at d = 64 (32 quarter-rate exp2 + ~100 full-rate ops against 16 MFMAs per tile and wave)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 c2 = {c, c}, mc2 = {-m_run * c, -m_run * c};
-    f32x2 ps2 = {0.f, 0.f};
+    const float mc = m_run * c;
+    float psum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; i += 2) {
-      f32x2 v = {s[i], s[i + 1]};
-      v = __builtin_elementwise_fma(v, c2, mc2);
-      v.x = __builtin_amdgcn_exp2f(v.x);
-      v.y = __builtin_amdgcn_exp2f(v.y);
-      ps2 += v;
-      s[i] = v.x;
-      s[i + 1] = v.y;
+    for (int i = 0; i < 32; ++i) {
+#if UR_ATTN_ABL == 1
+      s[i] = fmaf(s[i], c, -mc);
+#else
+      s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], c, -mc));
+#endif
+      psum += s[i];
     }
-    l_run += ps2.x + ps2.y;
+    l_run += psum;
 
     // ---- O^T += V^T P^T : 4 k-steps of 16 keys; P^T fragment = 8 consecutive accumulator registers ----
 #pragma unroll
@@ -211,7 +212,12 @@ __global__ __launch_bounds__(256, (D == 64 ? UR_ATTN_WAVES : 1)) void attn_fwd_k
       for (int f = 0; f < DF; ++f) {
         const int row = f * 32 + l31;
         const frag_t vf = *reinterpret_cast<const frag_t*>(vs + row * 128 + (((kk * 2 + hf) ^ ((row >> 1) & 7)) << 4));
+#if UR_ATTN_ABL == 2
+        if (f == 0 && kk == 0) oacc[f] = mfma16t(vf, pf, oacc[f]);
+        else oacc[f][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, vf).x) * s[kk * 8 + f];
+#else
         oacc[f] = mfma16t(vf, pf, oacc[f]);
+#endif
       }
     }
     if (more) store_tile(stage ^ 1);
