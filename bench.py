@@ -21,6 +21,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # multi-process GPU work: the host driver only supports dmabuf IPC
+
 import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0     # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
