@@ -176,6 +176,33 @@ int ur_attention_fwd(const void* q, const void* k, const void* vt, void* o, int 
                      int D, int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k,
                      long long bs_vt, long long bs_o, float scale, int dtype, ur_stream_t stream);
 
+/* ---- token-stationary fused chains (csrc/tchain.hip) ----------------------------------------------
+ * A wave keeps 32 tokens in registers through a whole chain of token-wise layers; the weights arrive as a pre-packed
+ * stream of ur_chain_tile_bytes()-byte tiles that are the LDS image of each layer (unirestore_amd/chain.py packs them:
+ * [row][128 B] blocks, XOR-swizzled slots, swap23-permuted output rows, LayerNorm folded, fp32 vectors in the tile tail).
+ * Shapes: C == 320 (UNet level 0) and T % 128 == 0; anything else returns UR_E_UNSUPPORTED / UR_E_INVALID and the caller
+ * uses the per-layer entry points above. */
+size_t ur_chain_tile_bytes(void);
+/* y[t,:] = x[t,:] + W2 . GEGLU(W1 . LayerNorm(x[t,:]) + b1) + b2: diffusers FeedForward(activation_fn="geglu") + norm3 + residual of
+ * BasicTransformerBlock (reached through /root/reference/src/modules/diffuie/base_model.py:137-160,184-198).  The 4C-wide
+ * hidden tensor never exists in memory.  stream_w: 3 * hidden/64 tiles. */
+int ur_ff_geglu_fused(const void* x, const void* stream_w, size_t stream_bytes, void* y, long long T, int C, int hidden, int ldx,
+                      int ldy, float ln_eps, int dtype, ur_stream_t stream);
+
+/* h0 = proj_in(GroupNorm(x)) (gn_ab: the per-image affine [N][2][C] from ur_groupnorm_finalize, applied to the fragments in
+ * registers) and q | k | v = to_q / to_k / to_v(LayerNorm1(h0)) of the block's self-attention: Transformer2DModel.norm + proj_in,
+ * BasicTransformerBlock.norm1 + attn1 projections (base_model.py:137-160 via diffusers).  h0, q, k: [T][C]; vt: [N][C][tokens_per_image]
+ * (V transposed, the layout ur_attention_fwd reads).  stream_w: 20 tiles. */
+int ur_transformer_head_fused(const void* x, const float* gn_ab, const void* stream_w, size_t stream_bytes, void* h0, void* q, void* k,
+                              void* vt, long long T, int tokens_per_image, int C, float ln_eps, int dtype, ur_stream_t stream);
+/* Everything behind the self-attention: h1 = h0 + to_out(o1); cross-attention over the CONSTANT context (its K / V are baked into
+ * the stream; tk <= 80 keys, heads x 64) with LayerNorm2 folded into to_q; h2 = h1 + to_out(o2); h3 = h2 + FF(LayerNorm3(h2));
+ * y = xres + proj_out(h3).  gn_part (optional): fp32 [N][tokens_per_image/128][C][2] partial (sum, sum of squares) of y for the
+ * GroupNorm of the next ResnetBlock2D (ur_groupnorm_finalize with parts = tokens_per_image/128).  stream_w: 25 + 3*hidden/64 tiles. */
+int ur_transformer_tail_fused(const void* o1, const void* h0, const void* xres, const void* stream_w, size_t stream_bytes, void* y,
+                              float* gn_part, long long T, int tokens_per_image, int C, int hidden, int heads, int tk, float ln_eps,
+                              float attn_scale, int dtype, ur_stream_t stream);
+
 /* ---- HBM-bound stencils / reductions / elementwise ---------------------------------------------*/
 /* depthwise 3x3 (pad 1) + bias, optional SimpleGate (out channels C/2): nafnet_arch.py:41-49,22-25 */
 int ur_dwconv3x3_nhwc(const void* x, const float* w9c, const float* bias, void* y, int N, int H, int W, int C,
