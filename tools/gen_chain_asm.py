@@ -150,8 +150,8 @@ def write(out):
     # FF1 epilogue vectors: (bias a | bias g | colsum a | colsum g) x 32 floats; lane half h is folded into the address operand
     # (one half-fragment u per block: 8 x float4 = 32 registers live at a time)
     txt += aux_block("TC_ASM_AUX_FF1", [vec * 4 + 16 * q for vec in (0, 32, 64, 96) for q in range(2)])
-    # a stage's bias (or LayerNorm column sums) for 10 half-fragments = 5 accumulator fragments: 8 floats each
-    txt += aux_block("TC_ASM_AUX_20", [u * 64 + q * 16 for u in range(10) for q in range(2)])
+    # a stage's bias for 4 half-fragments = 2 accumulator fragments: 8 floats each (32 registers live at a time)
+    txt += aux_block("TC_ASM_AUX_8", [u * 64 + q * 16 for u in range(4) for q in range(2)])
     # ONE fragment of a LayerNorm-folded stage: bias (floats 0..) for its two half-fragments, then column sums (floats 512..)
     txt += aux_block("TC_ASM_AUX_BC8", [base + u * 64 + q * 16 for base in (0, 2048) for u in range(2) for q in range(2)])
     open(out, "w").write(txt)

@@ -132,7 +132,7 @@ def pack_tail(wo1, bo1, wq2, g2, be2, wk2, wv2, ctx, wo2, bo2, w1, b1, w2, b2, g
     assert heads * d == c and d == 64 and tk <= 80 and wq2.shape == (c, c)
     tiles = gemm_tiles(wo1, dt, aux_last=bo1)
     wf, bf, cs = fold_ln(wq2, None, g2, be2, dt)
-    tiles += gemm_tiles(wf, dt)
+    wf16 = wf.to(dt)
     # context keys / values: computed from the 16-bit-rounded operands (as the per-layer path does), stored in the 16-bit type
     ctx16 = ctx.to(dt).float()
     kc = (ctx16 @ wk2.to(dt).float().t()).to(dt)                    # [Tk, C]
@@ -141,12 +141,15 @@ def pack_tail(wo1, bo1, wq2, g2, be2, wk2, wv2, ctx, wo2, bo2, w1, b1, w2, b2, g
     kpad[:tk] = kc
     vtp = torch.zeros(c, 128, dtype=dt, device=dev)
     vtp[:, :tk] = vc.t()
-    pk, pd = perm_rows(96).to(dev), perm_rows(d).to(dev)
+    pk, pd, p32 = perm_rows(96).to(dev), perm_rows(d).to(dev), _PERM32.to(dev)
+    out2 = gemm_tiles(wo2, dt, aux_last=bo2)                        # K slice hd of to_out2 = its tile hd
     for hd in range(heads):
-        blocks = [lds_block(kpad[pk][:, d * hd:d * hd + d].contiguous()),
-                  lds_block(vtp[d * hd + pd][:, 0:64].contiguous()), lds_block(vtp[d * hd + pd][:, 64:128].contiguous())]
-        tiles.append(_tile(blocks, _ln_aux(bf[d * hd:d * hd + d], cs[d * hd:d * hd + d])))
-    tiles += gemm_tiles(wo2, dt, aux_last=bo2)
+        ra, rb = d * hd + p32, d * hd + 32 + p32
+        qblocks = [lds_block(torch.cat([wf16[ra, 64 * kb:64 * kb + 64], wf16[rb, 64 * kb:64 * kb + 64]], 0)) for kb in range(c // 64)]
+        tiles.append(_tile(qblocks, _ln_aux(bf[d * hd:d * hd + d], cs[d * hd:d * hd + d])))
+        tiles.append(_tile([lds_block(kpad[pk][:, d * hd:d * hd + d].contiguous()),
+                            lds_block(vtp[d * hd + pd][:, 0:64].contiguous()), lds_block(vtp[d * hd + pd][:, 64:128].contiguous())]))
+        tiles.append(out2[hd])
     mlp = pack_mlp(w1, b1, w2, b2, g3, be3, dev, dt)
     tiles.append(mlp)
     tiles += gemm_tiles(w_out, dt, aux_last=b_out)

@@ -187,26 +187,24 @@ struct TChain {
                  : "v"(a)
                  : "memory");
   }
-  // 10 half-fragments (5 accumulator fragments from `f0`) of the fp32 vector at float offset `vec` of the aux area:
+  // 4 half-fragments (2 accumulator fragments from `f0`) of the fp32 vector at float offset `vec` of the aux area:
   // q[2*i], q[2*i+1] = the lane's 8 values for half-fragment 2*f0 + i
-  __device__ __forceinline__ void aux_vec10(unsigned slot, int vec, int f0, float4 (&q)[20]) const {
+  __device__ __forceinline__ void aux_vec4(unsigned slot, int vec, int f0, float4 (&q)[8]) const {
     const unsigned a = slot + TC_WB + (vec + 32 * f0 + 8 * h) * 4;
-    asm volatile(TC_ASM_AUX_20
-                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7]), "=&v"(q[8]),
-                   "=&v"(q[9]), "=&v"(q[10]), "=&v"(q[11]), "=&v"(q[12]), "=&v"(q[13]), "=&v"(q[14]), "=&v"(q[15]), "=&v"(q[16]),
-                   "=&v"(q[17]), "=&v"(q[18]), "=&v"(q[19])
+    asm volatile(TC_ASM_AUX_8
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
                  : "v"(a)
                  : "memory");
   }
 
   // cross-attention scores of one head: S^T[96 keys][32 tokens] = K_h (3 fragments of 32 key rows x 64 d at the tile start) . q^T
-  __device__ __forceinline__ void att_s(f32x16 (&sc)[3], const frag_t& q0, const frag_t& q1, const frag_t& q2, const frag_t& q3, unsigned slot) {
+  __device__ __forceinline__ void att_s(f32x16& s0, f32x16& s1, f32x16& s2, const frag_t& q0, const frag_t& q1, const frag_t& q2, const frag_t& q3, unsigned slot) {
     const unsigned a0 = slot + aoff[0], a1 = slot + aoff[1], a2 = slot + aoff[2], a3 = slot + aoff[3];
     frag_t t0, t1, t2, t3, t4, t5, t6, t7;
     unsigned so, ld;
     dma_args(so, ld);
     TC_MFMA_BLOCK(TC_ASM_ATT_S,
-                  : "+a"(sc[0]), "+a"(sc[1]), "+a"(sc[2]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6),
+                  : "+a"(s0), "+a"(s1), "+a"(s2), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6),
                     "=&v"(t7), "+s"(so), "+s"(ld)
                   : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs)
                   : "memory");
@@ -251,12 +249,12 @@ struct TChain {
   template <bool RES>
   __device__ __forceinline__ void bias_res_pack(const f32x16 (&acc)[10], unsigned slot, const frag_t (&res)[20], frag_t (&out)[20]) const {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float4 q[20];
-      aux_vec10(slot, 0, 5 * half, q);
+    for (int fp = 0; fp < 5; ++fp) {                     // two fragments at a time: 32 registers of bias values live
+      float4 q[8];
+      aux_vec4(slot, 0, 2 * fp, q);
 #pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        const int f = 5 * half + (i >> 1), u = i & 1;
+      for (int i = 0; i < 4; ++i) {
+        const int f = 2 * fp + (i >> 1), u = i & 1;
         float r[8], v[8];
         if constexpr (RES) unpack(res[2 * f + u], r);
 #pragma unroll
@@ -294,7 +292,9 @@ __device__ __forceinline__ void row_stats(const typename Frag<F16>::type (&x)[KS
   rstd = rsqrtf(q * (1.0f / (16 * KS)) + eps);
 }
 
-// FeedForward(GEGLU) over the LayerNorm of xb (raw fragments; LayerNorm folded: mean / rstd given): acc = W2 . GEGLU(...) (no b2).
+// FeedForward(GEGLU) over the LayerNorm of xb (raw fragments; LayerNorm folded: mean / rstd given): acc += W2 . GEGLU(...) (no b2);
+// the caller zeroes acc (ONE asm instance of the FF2 phase in the loop: with a second, zero-initialising one for the first chunk
+// hipcc's register allocation of the whole kernel degraded to ~100 spilled registers).
 // Stream per 64 hidden units: [FF1 tile: 5 blocks of (32 a rows | 32 g rows) x 64 k; aux = ba | bg | colsum_a | colsum_g]
 //                             [FF1 tile of the next 32 units]  [FF2 tile: 320 rows x 64 k; aux of the LAST one = b2]
 // Returns the LDS address of the last FF2 tile.
@@ -327,8 +327,7 @@ __device__ __forceinline__ unsigned ff_stage(TChain<F16>& tc, f32x16 (&acc)[10],
       }
     }
     last = tc.acquire();
-    if (c == 0) tc.template gemm_tile<true>(acc, hid[0], hid[1], hid[2], hid[3], last);
-    else tc.template gemm_tile<false>(acc, hid[0], hid[1], hid[2], hid[3], last);
+    tc.template gemm_tile<false>(acc, hid[0], hid[1], hid[2], hid[3], last);     // (acc starts at zero: see the callers)
   }
   return last;
 }
@@ -391,6 +390,14 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
 }
 
 
+// the lane's token index, recomputed from the hardware ids behind an opaque barrier (keeping the value computed at kernel entry
+// alive through the whole chain costs registers that end up in scratch)
+__device__ __forceinline__ long long token_again() {
+  unsigned t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return (long long)blockIdx.x * TC_TOK + (t >> 6) * 32 + (t & 31);
+}
+
 template <bool F16>
 __device__ __forceinline__ void launder(typename Frag<F16>::type (&x)[20]) {
   // opaque to the optimiser: hipcc otherwise keeps the 160 fp32 values a LayerNorm-statistics pass unpacked alive (spilled) until
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void tchain_head_kernel(const HeadP p) {
   const long long tok0 = (long long)blockIdx.x * TC_TOK;
   const long long tok = tok0 + tc.wid * 32 + (tc.lane & 31);
   const int img = (int)(tok0 / p.tok_per_img);
-  frag_t xb[20], of[20];
+  frag_t xb[20];
   load_frags<F16>(p.x, tok, C, tc.h, xb);
   {
     const float* ap = p.ab + (long long)img * 2 * C + 8 * tc.h;
@@ -438,23 +445,33 @@ __global__ __launch_bounds__(256, 1) void tchain_head_kernel(const HeadP p) {
       v[0] = fmaf(v[0], a0.x, b0.x); v[1] = fmaf(v[1], a0.y, b0.y); v[2] = fmaf(v[2], a0.z, b0.z); v[3] = fmaf(v[3], a0.w, b0.w);
       v[4] = fmaf(v[4], a1.x, b1.x); v[5] = fmaf(v[5], a1.y, b1.y); v[6] = fmaf(v[6], a1.z, b1.z); v[7] = fmaf(v[7], a1.w, b1.w);
       xb[s] = tc.pack(v);
+      if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // (hipcc otherwise hoists all 80 affine loads = 320 registers and spills them)
     }
   }
   f32x16 acc[10];
   zero_acc(acc);
   unsigned slot = tc.gemm_stage(acc, xb);
   tc.template bias_res_pack<false>(acc, slot, xb, xb);               // h0 (no residual)
-  store_frags<F16>(p.h0, tok, C, tc.h, xb);                          // 20 stores
+  store_frags<F16>(p.h0, token_again(), C, tc.h, xb);                // 20 stores
   float mean, rstd;
   row_stats<F16, 20>(xb, p.eps, mean, rstd);
   launder<F16>(xb);
 #pragma unroll
   for (int part = 0; part < 3; ++part) {
     slot = tc.template gemm_stage<20>(acc, xb);
+    uint16_t* op = (part == 0 ? p.q : p.k) + token_again() * C + 8 * tc.h;
 #pragma unroll
-    for (int f = 0; f < 10; ++f) tc.ln_pack(acc[f], slot, f, mean, rstd, of[2 * f], of[2 * f + 1]);
-    if (part == 0) store_frags<F16>(p.q, tok, C, tc.h, of);
-    if (part == 1) store_frags<F16>(p.k, tok, C, tc.h, of);
+    for (int f = 0; f < 10; ++f) {
+      frag_t o0, o1;
+      tc.ln_pack(acc[f], slot, f, mean, rstd, o0, o1);
+      if (part < 2) {                                                // q, k: straight out (two 16-byte stores per fragment)
+        *reinterpret_cast<frag_t*>(op + 32 * f) = o0;
+        *reinterpret_cast<frag_t*>(op + 32 * f + 16) = o1;
+      } else {                                                       // v: h0's fragments are dead now - keep v in their registers
+        xb[2 * f] = o0;
+        xb[2 * f + 1] = o1;
+      }
+    }
   }
   // v^T: transpose this wave's [32 tokens][320 channels] through LDS (the ring is free: the stream has ended)
   tc.drain();
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void tchain_head_kernel(const HeadP p) {
   const int j = tc.lane & 31;
 #pragma unroll
   for (int s = 0; s < 20; ++s) {
-    const uint4 w = __builtin_bit_cast(uint4, of[s]);
+    const uint4 w = __builtin_bit_cast(uint4, xb[s]);
     const unsigned wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -486,9 +503,9 @@ __global__ __launch_bounds__(256, 1) void tchain_head_kernel(const HeadP p) {
 // kind TAIL: everything of a BasicTransformerBlock behind the self-attention + Transformer2DModel.proj_out:
 //   h1 = h0 + to_out1(o1) + b;  q2 = to_q2(LayerNorm2(h1));  o2 = softmax(q2 Kc^T / 8) Vc per head (constant context, <= 80 keys);
 //   h2 = h1 + to_out2(o2) + b;  h3 = h2 + FF(LayerNorm3(h2));  y = x + proj_out(h3) + b;  GroupNorm partial sums of y.
-// Stream: to_out1 (5 tiles, aux = bias) | to_q2 (5, LayerNorm folded, no aux) | 5 head tiles (K_h 96 x 64 at byte 0, V^T_h as two
-// [64][128 B] blocks at bytes 12288 / 20480; aux = this head's 64 bias' values at floats 0.. and column sums at 512..) |
-// to_out2 (5, bias) | FF (3 per 64 hidden units) | proj_out (5, bias).
+// Stream: to_out1 (5 tiles, aux = bias) | per head: [to_q2 rows of the head, LayerNorm folded: 5 blocks of (32 | 32 rows) x 64 k,
+// aux = bias' at floats 0..63 and column sums at 512..575] [K_h 96 x 64 at byte 0, V^T_h as two [64][128 B] blocks at bytes
+// 12288 / 20480] [to_out2 K slice of the head: 320 rows x 64 k; aux of the last = bias] | FF (3 per 64 hidden units) | proj_out (5, bias).
 struct TailP {
   const unsigned char* stream;
   const uint16_t* o1;            // [T][C] self-attention output
@@ -511,54 +528,65 @@ __global__ __launch_bounds__(256, 1) void tchain_tail_kernel(const TailP p) {
   const long long tok = tok0 + tc.wid * 32 + (tc.lane & 31);
   frag_t hb[20], xq[20];
   load_frags<F16>(p.o1, tok, C, tc.h, xq);
-  load_frags<F16>(p.h0, tok, C, tc.h, hb);
-  f32x16 acc[10], ag[2], sc[3];
+  f32x16 acc[10], ag[2], sc2[1];                      // scores of a head: keys 0-63 in ag (q is packed by then), keys 64-95 in sc2
   zero_acc(acc);
   zero_acc(ag);
-  zero_acc(sc);
-  // h1 = h0 + to_out1(o1)
-  unsigned slot = tc.gemm_stage(acc, xq);
+  zero_acc(sc2);
+  // h1 = h0 + to_out1(o1) + b; the residual h0 is fetched behind the 4th of the stage's 5 tiles (80 registers less during the others)
+  unsigned slot = tc.acquire();
+  tc.template gemm_tile<true>(acc, xq[0], xq[1], xq[2], xq[3], slot);
+#pragma unroll
+  for (int kt = 1; kt < 5; ++kt) {
+    slot = tc.acquire();
+    tc.template gemm_tile<false>(acc, xq[4 * kt], xq[4 * kt + 1], xq[4 * kt + 2], xq[4 * kt + 3], slot);
+    if (kt == 3) load_frags<F16>(p.h0, token_again(), C, tc.h, hb);
+  }
   tc.template bias_res_pack<true>(acc, slot, hb, hb);
-  // q2 = to_q2(LN2(h1)): the raw products stay in the accumulators, each head applies the LayerNorm transform to its 64 channels
+  // cross-attention, head by head: q_h = to_q2(LN2(h1))[64 channels of head h] (an FF1-shaped tile: 2 fragments over K = 320,
+  // LayerNorm folded) -> scores over the constant keys -> softmax -> P.V -> o2_h (4 fragments) is at once the K slice h of
+  // to_out2, accumulated into `acc`: no [token][320] intermediate of the attention exists, not even in registers.
   float mean, rstd;
   row_stats<F16, 20>(hb, p.eps, mean, rstd);
   launder<F16>(hb);
-  tc.gemm_stage(acc, hb);
 #pragma unroll
   for (int hd = 0; hd < 5; ++hd) {
     slot = tc.acquire();
+    tc.ff1_tile(ag, hb, slot);
     frag_t qf[4];
-    tc.ln_pack(acc[2 * hd], slot, 0, mean, rstd, qf[0], qf[1]);
-    tc.ln_pack(acc[2 * hd + 1], slot, 1, mean, rstd, qf[2], qf[3]);
-    tc.att_s(sc, qf[0], qf[1], qf[2], qf[3], slot);
-    // softmax over the keys: the lane holds 48 of its token's 96 scores (key = 32 kf + 16 (r >> 3) + 8 h + (r & 7)), the other half's lane the rest
-    float sv[48];
+    tc.ln_pack(ag[0], slot, 0, mean, rstd, qf[0], qf[1]);
+    tc.ln_pack(ag[1], slot, 1, mean, rstd, qf[2], qf[3]);
+    slot = tc.acquire();
+    tc.att_s(ag[0], ag[1], sc2[0], qf[0], qf[1], qf[2], qf[3], slot);
+    // softmax over the keys: the lane holds 48 of its token's 96 scores (key = 32 kf + 16 (r >> 3) + 8 h + (r & 7)), the other
+    // half's lane the rest.  Two passes over the accumulator registers (maximum, then exp2 + sum + pack): no 48-float copy.
     float mx = -INFINITY;
 #pragma unroll
     for (int kf = 0; kf < 3; ++kf)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = 32 * kf + 16 * (r >> 3) + 8 * tc.h + (r & 7);
-        const float v = key < p.tk ? sc[kf][r] : -INFINITY;
-        sv[kf * 16 + r] = v;
-        mx = fmaxf(mx, v);
+        mx = fmaxf(mx, key < p.tk ? (kf < 2 ? ag[kf & 1][r] : sc2[0][r]) : -INFINITY);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mc = mx * p.scale_log2e;
     float l = 0.f;
-#pragma unroll
-    for (int i = 0; i < 48; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], p.scale_log2e, -mc)); l += sv[i]; }
-    l += __shfl_xor(l, 32, 64);
     frag_t pf[5];
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) {
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = sv[(ks >> 1) * 16 + 8 * (ks & 1) + e];
+      for (int e = 0; e < 8; ++e) {
+        const int key = 16 * ks + 8 * tc.h + e;
+        const float sv = ks < 4 ? ag[(ks >> 1) & 1][8 * (ks & 1) + e] : sc2[0][e];
+        v[e] = key < p.tk ? __builtin_amdgcn_exp2f(fmaf(sv, p.scale_log2e, -mc)) : 0.f;
+        l += v[e];
+      }
       pf[ks] = tc.pack(v);
     }
+    l += __shfl_xor(l, 32, 64);
     tc.att_pv(ag, pf, slot);
     const float inv = __builtin_amdgcn_rcpf(l);
+    frag_t of[4];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -566,23 +594,26 @@ __global__ __launch_bounds__(256, 1) void tchain_tail_kernel(const TailP p) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = ag[f][8 * u + e] * inv;
-        xq[4 * hd + 2 * f + u] = tc.pack(v);
+        of[2 * f + u] = tc.pack(v);
       }
+    slot = tc.acquire();
+    if (hd == 0) tc.template gemm_tile<true>(acc, of[0], of[1], of[2], of[3], slot);
+    else tc.template gemm_tile<false>(acc, of[0], of[1], of[2], of[3], slot);
   }
-  // h2 = h1 + to_out2(o2)
-  slot = tc.gemm_stage(acc, xq);
+  // h2 = h1 + to_out2(o2) + b (bias: aux of the last to_out2 tile)
   tc.template bias_res_pack<true>(acc, slot, hb, hb);
   // h3 = h2 + FF(LN3(h2))
   row_stats<F16, 20>(hb, p.eps, mean, rstd);
   launder<F16>(hb);
+  zero_acc(acc);
   slot = ff_stage<F16>(tc, acc, ag, hb, mean, rstd, p.hidden / 64);
   tc.template bias_res_pack<true>(acc, slot, hb, hb);
-  // y = x + proj_out(h3)
-  load_frags<F16>(p.xres, tok, C, tc.h, xq);
+  // y = x + proj_out(h3) + b
   slot = tc.gemm_stage(acc, hb);
-  launder<F16>(xq);                                  // (the loads are waited for here, behind the stage)
+  const long long tok2 = token_again();
+  load_frags<F16>(p.xres, tok2, C, tc.h, xq);        // (after the stage: 80 more live registers during it would spill)
   tc.template bias_res_pack<true>(acc, slot, xq, xq);
-  store_frags<F16>(p.y, tok, C, tc.h, xq);
+  store_frags<F16>(p.y, tok2, C, tc.h, xq);
   tc.drain();                                        // no LDS-DMA may outlive the workgroup; the ring memory is free now
   if (p.gn_part) {
     // GroupNorm statistics of the 16-bit values just written: tile -> LDS [128 tokens][656 B] (row pad: conflict-free column reads),

@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import chain, ops
 from ..ops import UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_SILU
 
 DEV = "cuda"
@@ -29,6 +29,10 @@ SIDE_STREAM = os.environ.get("UR_CSCE_STREAM", "0") == "1"
 side_stream = ops.side_stream
 
 FUSE_LN = __import__("os").environ.get("UR_FUSE_LN", "1") == "1"   # LayerNorm folded into the consuming GEMMs
+# Token-stationary fused chains (csrc/tchain.hip) for the 320-channel transformer blocks: 3 launches per Transformer2DModel
+# (HEAD chain, self-attention, TAIL chain) instead of 12.  UR_CHAIN=0 selects the per-layer path (A/B, and the shapes the
+# chains do not cover take it anyway).
+CHAIN = os.environ.get("UR_CHAIN", "1") == "1"
 
 
 class _NoEager:
@@ -380,12 +384,49 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(c, heads, cross_dim)])
         self.proj_out = Linear(c, c)
 
+    def _chain_streams(self, ctx):
+        """Weight streams of the HEAD / TAIL chains for the current 16-bit type (packed once; dropped by invalidate_packed)."""
+        key = ("cache", "chain", ops.act_dtype())
+        if key not in self.__dict__:
+            b = self.transformer_blocks[0]
+            ff1, ff2 = b.ff.net[0].proj, b.ff.net[2]
+            head = chain.pack_head(self.proj_in.weight, self.proj_in.bias, b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight,
+                                   b.norm1.weight, b.norm1.bias, DEV)
+            tail = chain.pack_tail(b.attn1.to_out[0].weight, b.attn1.to_out[0].bias, b.attn2.to_q.weight, b.norm2.weight, b.norm2.bias,
+                                   b.attn2.to_k.weight, b.attn2.to_v.weight, ctx[0].float(), b.attn2.to_out[0].weight, b.attn2.to_out[0].bias,
+                                   ff1.weight, ff1.bias, ff2.weight, ff2.bias, b.norm3.weight, b.norm3.bias,
+                                   self.proj_out.weight, self.proj_out.bias, b.attn2.heads, DEV)
+            self.__dict__[key] = (head, tail)
+        return self.__dict__[key]
+
+    def _chain_ok(self, x, ctx):
+        b = self.transformer_blocks[0]
+        n, hh, ww, c = x.shape
+        return (CHAIN and c == chain.CHAIN_C and (hh * ww) % chain.CHAIN_TOK == 0 and b.attn1.heads == 5 and b.attn2.heads == 5 and
+                ctx.shape[0] == 1 and ctx.shape[1] <= 80 and b.attn1.to_q.bias is None and b.attn2.to_q.bias is None and
+                b.norm1.eps == b.norm2.eps == b.norm3.eps and ff_hidden(b) == 4 * c and x.is_contiguous())
+
     def run(self, x, ctx):
         n, hh, ww, c = x.shape
+        if self._chain_ok(x, ctx):
+            # HEAD chain: GroupNorm apply + proj_in + LayerNorm1-folded q / k / v^T; flash self-attention; TAIL chain: everything else,
+            # leaving the GroupNorm partial sums of the next resnet's norm1 (base_model.py:137-160,184-198 via diffusers)
+            b = self.transformer_blocks[0]
+            head, tail = self._chain_streams(ctx)
+            t, heads = hh * ww, b.attn1.heads
+            d = c // heads
+            h0, q, k, vt = chain.transformer_head_fused(x, self.norm.coeffs(x), head, n, b.norm1.eps)
+            o1 = ops.attention(q, k, vt, heads, d, t, t, 1.0 / math.sqrt(d), ldq=c, ldk=c, bs_q=t * c, bs_k=t * c, bs_vt=c * t, batch=n)
+            y = chain.transformer_tail_fused(o1, h0, x, tail, n, 4 * c, heads, ctx.shape[1], b.norm1.eps, 1.0 / math.sqrt(d))
+            return ops.carry(y, y.view(n, hh, ww, c))
         h = ops.linear(self.norm.run(x).view(n, hh * ww, c), self.proj_in.packed(), rows=FUSE_LN)
         h = self.transformer_blocks[0].run(h, ctx)
         o = ops.linear(h, self.proj_out.packed(), residual=x.view(n, hh * ww, c), gn=True, gn_hw=(n, hh * ww))
         return ops.carry(o, o.view(n, hh, ww, c))
+
+
+def ff_hidden(block) -> int:
+    return block.ff.net[2].in_features
 
 
 # ----------------------------------------------------------------------------------------------- blocks
