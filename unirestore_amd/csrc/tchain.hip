@@ -108,7 +108,7 @@ struct TChain {
     unsigned so, ld;
     dma_args(so, ld);
     if constexpr (UR_CHAIN_ABL == 2) return;
-    asm volatile(TC_ASM_DMA : "+s"(so), "+s"(ld) : "v"(voff), "s"(rs) : "memory");
+    asm volatile(TC_ASM_DMA : "+s"(so), "+s"(ld) : "v"(voff), "s"(rs) : "memory", "scc");      // (s_add_u32 inside: SCC is clobbered)
   }
   // Tile `tc` is ready in its slot for every wave, and the slot of the tile before it is free again (the phase that follows
   // refills it with tile tc + 2).  In flight at this point: tile tc and tile tc + 1, 11 pieces each per wave, in issue order -
@@ -140,7 +140,7 @@ struct TChain {
     : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]),  \
       "+a"(acc[9]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "+s"(so), "+s"(ld)       \
     : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs)                                    \
-    : "memory"
+    : "memory", "scc"
     if constexpr (Z) TC_MFMA_BLOCK(TC_ASM_GEMM_N10_Z, TC_GEMM_OPERANDS);
     else TC_MFMA_BLOCK(TC_ASM_GEMM_N10, TC_GEMM_OPERANDS);
 #undef TC_GEMM_OPERANDS
@@ -170,7 +170,7 @@ struct TChain {
                     "+s"(so), "+s"(ld)
                   : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(xb[4]), "v"(xb[5]), "v"(xb[6]), "v"(xb[7]), "v"(xb[8]), "v"(xb[9]),
                     "v"(xb[10]), "v"(xb[11]), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs)
-                  : "memory");
+                  : "memory", "scc");
     TC_MFMA_BLOCK(TC_ASM_FF1_B,
                   : "+a"(ag[0]), "+a"(ag[1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
                   : "v"(xb[12]), "v"(xb[13]), "v"(xb[14]), "v"(xb[15]), "v"(xb[16]), "v"(xb[17]), "v"(xb[18]), "v"(xb[19]),
@@ -207,7 +207,7 @@ struct TChain {
                   : "+a"(s0), "+a"(s1), "+a"(s2), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6),
                     "=&v"(t7), "+s"(so), "+s"(ld)
                   : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs)
-                  : "memory");
+                  : "memory", "scc");
   }
   // O^T[64 d][32 tokens] = V^T_h (two [64 d rows][128 B] blocks at bytes 12288 / 20480: keys 0-63 | 64-127) . P^T, first 80 keys
   __device__ __forceinline__ void att_pv(f32x16 (&o)[2], const frag_t (&pf)[5], unsigned slot) {
