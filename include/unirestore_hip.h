@@ -77,7 +77,7 @@ typedef struct ur_conv_desc {
                            conv's loader; zero padding stays zero).  Only where ur_conv_plan.prologue_ok */
   int gn_silu;          /* 1: SiLU after the gn_ab affine */
   float* row_stats;     /* fp32 [parts][M][2] = per-row (sum, sum of squares) of this GEMM's output, one partial plane per N
-                           tile (plain stores; parts = ur_conv2d_row_stat_parts(desc)): the LayerNorm statistics of the
+                           tile (plain stores; parts = ur_conv_plan.row_stat_parts from ur_conv2d_plan): the LayerNorm statistics of the
                            GEMM that consumes y (BasicTransformerBlock norm1-3) or NULL */
   const float* ln_stats;  /* fp32 [ln_parts][M][2] row sums of x (a producer's row_stats): this GEMM computes W.LayerNorm(x) as
                              rstd*(acc - mean*ln_colsum[n]) + bias[n] with w = W*gamma, bias = W.beta + b prefolded; or NULL */

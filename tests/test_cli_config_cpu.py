@@ -68,7 +68,11 @@ data:
   class_path: data.DatasetEngine
   init_args: {task: mtl, train: {type: all, resolution: 512, batch_size: 1}, val: {type: val, val_list: [], batch_size: 1}}
 """)
-    r = cli.resolve(cli.load_config(str(p), ["model.init_args.model_kwargs.cnet.num_inference_steps=4"]))
+    with pytest.raises(ValueError, match="allow-16bit"):                 # precision 32 is refused, never silently narrowed
+        cli.resolve(cli.load_config(str(p)))
+    with pytest.warns(UserWarning, match="fp16"):
+        r = cli.resolve(cli.load_config(str(p), ["model.init_args.model_kwargs.cnet.num_inference_steps=4"]), allow_16bit=True)
+    assert r["dtype"] == "fp16"
     assert r["model_kwargs"]["cnet"]["num_inference_steps"] == 4 and r["model_kwargs"]["cnet"]["ckpt_path"] is None
     assert r["devices"] == 2 and r["data_args"]["resolution"] == [512, 512] and r["caller_args"]["need_crop"] is True
     with pytest.raises(ValueError):
@@ -120,5 +124,36 @@ def test_ssim_and_psnr_match_the_textbook_definitions():
 
     assert abs(runner.ssim(y, x) - sk_ssim(y, x)) < 1e-9
     assert abs(runner.ssim(x, x) - 1.0) < 1e-12
-    mse = float(((y.double() - x.double()) ** 2).mean())
-    assert abs(runner.psnr(y, x) - 10 * np.log10(1.0 / mse)) < 1e-9
+    # PSNR: skimage's per-image value, averaged over the images (the reference's SKPSNR sums per-sample PSNRs and divides by the
+    # image count, eval_image_restoration.py:266-278) - NOT the PSNR of the batch-mean MSE; the two images differ on purpose
+    y2 = y.clone()
+    y2[1] = (x[1] + 0.3 * torch.randn(x[1].shape, generator=g)).clamp(0, 1)
+    per = [10 * np.log10(1.0 / float(((y2[n].double() - x[n].double()) ** 2).mean())) for n in range(2)]
+    assert abs(per[0] - per[1]) > 3.0
+    assert abs(runner.psnr(y2, x) - float(np.mean(per))) < 1e-9
+    assert torch.allclose(runner.psnr_per_image(y2, x), torch.tensor(per, dtype=torch.float64), atol=1e-9)
+    batch_mse = float(((y2.double() - x.double()) ** 2).mean())
+    assert abs(runner.psnr(y2, x) - 10 * np.log10(1.0 / batch_mse)) > 0.5          # the old (wrong) definition differs
+
+
+def test_lit_metrics_accumulate_per_image_and_ir_task():
+    """LitUniFIE's metric states: sum of per-image PSNR / image count; the IR evaluator restores with the 'ir' prompt whatever tag
+    the batch carries (eval_image_restoration.py:70)."""
+    from unirestore_amd import runner
+
+    class Fake:
+        calls = []
+
+        def forward(self, imgs, task, quantize=False):
+            Fake.calls.append(task)
+            return imgs * 0.9
+    lit = runner.LitUniFIE(dict(tedit=dict(task=["ir", "seg"])), model=Fake(), need_crop=False)
+    g = torch.Generator().manual_seed(1)
+    hq = torch.rand(3, 3, 16, 16, generator=g)
+    lq = hq.clone()
+    lq[2] = lq[2] * 0.5
+    lit.validation_step((lq, hq, None, ["a", "b", "c"], "seg"))
+    assert Fake.calls == ["ir"]
+    m = lit.metrics()
+    per = runner.psnr_per_image(lq * 0.9, hq)
+    assert m["images"] == 3 and abs(m["val_lq/psnr"] - float(per.mean())) < 1e-9

@@ -30,3 +30,14 @@ for dtn in ("bf16", "fp16"):
     fl = 2.0 * T * C * H * 3
     print(f"[{dtn}] MLP 32768x320 (hidden 1280): fused {t_f:7.1f} us ({fl / t_f / 1e6:6.0f} TF/s, weights {st.numel() * (T // 128) / t_f / 1e3:6.0f} GB/s L2->LDS)"
           f"   per-layer (2 launches) {t_p:7.1f} us   rel diff fused vs per-layer {d:.2e}")
+
+if os.environ.get("UR_CHAIN_STAMPS"):        # an ablation-6 build: cycle stamps of FF chunk 10 of workgroup 17, per wave
+    dt = ops.set_dtype("bf16")
+    x = (torch.randn(T, C, device="cuda") * 1.5).to(dt)
+    y = chain.ff_geglu_fused(x, st if st.dtype == torch.uint8 else st, H, 1e-5)
+    torch.cuda.synchronize()
+    raw = y.view(torch.int16).reshape(-1)[(T - 128) * C:].view(torch.int64)[:64].cpu().reshape(4, 16)[:, :9]
+    names = ["start", "acq1", "ff1 a", "epi a", "acq2", "ff1 b", "epi b", "acq3", "ff2"]
+    for w in range(4):
+        d = (raw[w][1:] - raw[w][:-1]).tolist()
+        print(f"wave {w}: " + "  ".join(f"{n}:{v}" for n, v in zip(names[1:], d)) + f"   chunk total {int(raw[w][8] - raw[w][0])}")

@@ -12,14 +12,14 @@ Each phase is one `asm volatile` block:
 Operands stay compiler-allocated ("+a" accumulators, "v" fragments): no hand-owned registers, no clobber lists.
 
 Operand numbering inside a block: accumulators %0.., the temporaries, the B fragments, the LDS address VGPRs, then (DMA blocks)
-voffset VGPR, buffer descriptor (4 SGPRs), soffset SGPR ("+s", advanced by the block), LDS base SGPR ("+s", advanced).
+voffset VGPR, buffer descriptor (4 SGPRs), wave id SGPR; soffset SGPR and LDS base SGPR are "+s" outputs (advanced by the block).
 The MFMA mnemonic is a macro argument (bf16 / f16 objects share the schedule).
 
 Run:  python tools/gen_chain_asm.py   (rewrites unirestore_amd/csrc/tchain_asm.inc)
 """
 import os
 
-DEPTH = 8
+DEPTH = 7
 PIECES = 11            # 1-KiB LDS-DMA pieces per wave per tile (4 waves x 11 KiB = one 44-KiB tile)
 
 
@@ -67,9 +67,10 @@ def block(name, steps, n_acc, n_b, n_addr, pad=True, depth=DEPTH, zero_first=Fal
         nxt += 2
     o_b, o_addr = nxt, nxt + n_b
     nxt += n_b + n_addr
+    o_wid = None
     if dma:
-        o_vo, o_rs = nxt, nxt + 1
-        nxt += 2
+        o_vo, o_rs, o_wid = nxt, nxt + 1, nxt + 2
+        nxt += 3
     assert nxt <= 30, (name, nxt)
     n = len(steps)
     lines = ["s_waitcnt lgkmcnt(0)"]
@@ -80,10 +81,14 @@ def block(name, steps, n_acc, n_b, n_addr, pad=True, depth=DEPTH, zero_first=Fal
 
     for i in range(min(depth, n)):
         lines.append(rd(i))
-    dma_after = {}
+    # DMA: wave w of the workgroup issues ALL its 11 pieces in one burst behind MFMA number ~ (w + 1) * n / 4 (runtime branch on
+    # the wave id): the four waves share ONE texture-address path per CU (64 B/clk: 16+ cycles per 1-KiB piece), so pieces issued
+    # by all four at the same point of the phase queue up and each costs its wave ~80 cycles of issue; staggered, a wave stalls for
+    # its own ~200 cycles while the other three SIMDs keep multiplying.
+    dma_at = {}
     if dma:
-        for j in range(PIECES):
-            dma_after.setdefault(min(n - 1, (j * n) // PIECES), []).append(j)
+        for w in range(4):
+            dma_at[min(n - 1, ((w + 1) * n) // 4 - 1)] = w
     seen = set()
     for i, (a, b, ad, imm) in enumerate(steps):
         issued = min(n, i + depth)
@@ -93,13 +98,17 @@ def block(name, steps, n_acc, n_b, n_addr, pad=True, depth=DEPTH, zero_first=Fal
         lines.append(f"@MN@ %{o_acc + a}, %{o_tmp + i % depth}, %{o_b + b}, {srcc}")
         if i + depth < n:
             lines.append(rd(i + depth))
-        for j in dma_after.get(i, []):
-            lines += dma_lines(j, o_vo, o_rs, o_so, o_ld)
+        if i in dma_at:
+            w = dma_at[i]
+            lines += [f"s_cmp_lg_u32 %{o_wid}, {w}", f"s_cbranch_scc1 .Ltc%=_{w}"]
+            for j in range(PIECES):
+                lines += dma_lines(j, o_vo, o_rs, o_so, o_ld)
+            lines.append(f".Ltc%=_{w}:")
     if pad:
         lines.append("s_nop 15")          # MFMA result -> VALU / accvgpr read of the same registers (software-managed hazard)
     hdr = f"{n} MFMAs, {n_acc} accumulators (%0..), {depth} temporaries (%{o_tmp}..), {n_b} B fragments (%{o_b}..), {n_addr} addresses (%{o_addr}..)"
     if dma:
-        hdr += f", DMA: soffset %{o_so}, lds base %{o_ld}, voffset %{o_vo}, descriptor %{o_rs}"
+        hdr += f", DMA: soffset %{o_so}, lds base %{o_ld}, voffset %{o_vo}, descriptor %{o_rs}, wave id %{o_wid}"
     return fmt(name, hdr, lines)
 
 
@@ -112,12 +121,14 @@ def dma_block(name):
 
 
 def aux_block(name, offsets):
-    """fp32 vectors of a tile's aux area -> registers: len(offsets) ds_read_b128 at address operand + immediate, waited for inside
-    the block (outputs are early-clobber: the statement is complete when it ends).  hipcc must not see these reads: a
-    compiler-visible ds_read behind an LDS-DMA makes it drain the whole DMA queue (s_waitcnt vmcnt(0)) first."""
+    """fp32 vectors of a tile's aux area -> registers: len(offsets) ds_read_b128 at (address operand %n) + (constant operand %n+1)
+    + immediate, waited for inside the block (outputs are early-clobber: the statement is complete when it ends).  The
+    fragment-dependent part of the offset is a compile-time constant OPERAND: one address register (aux base + lane half) serves
+    every fragment of a tile - hipcc otherwise keeps one address per fragment alive and spills them.  hipcc must not see these
+    reads: a compiler-visible ds_read behind an LDS-DMA makes it drain the whole DMA queue (s_waitcnt vmcnt(0)) first."""
     n = len(offsets)
-    lines = [f"ds_read_b128 %{i}, %{n} offset:{off}" for i, off in enumerate(offsets)] + ["s_waitcnt lgkmcnt(0)"]
-    return fmt(name, f"{n} x 16 bytes of the aux area (%0..%{n - 1}), address %{n}", lines, has_mn=False)
+    lines = [f"ds_read_b128 %{i}, %{n} offset:%c{n + 1}+{off}" for i, off in enumerate(offsets)] + ["s_waitcnt lgkmcnt(0)"]
+    return fmt(name, f"{n} x 16 bytes of the aux area (%0..%{n - 1}), address %{n}, constant byte offset %{n + 1}", lines, has_mn=False)
 
 
 def gemm_ktile(nf, ks=4):

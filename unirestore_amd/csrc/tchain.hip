@@ -27,7 +27,7 @@
 #include "common.h"
 #ifndef UR_CHAIN_ABL
 #define UR_CHAIN_ABL 0      // timing-only ablations for A/B builds (tools/bench_chain.py): 1 = no MFMA phases, 2 = no weight DMA, 3 = no GELU,
-#endif                      // 4 = MFMA phases without their fragment reads, 5 = without their MFMAs
+#endif                      // 4 = MFMA phases without their fragment reads, 5 = without their MFMAs, 6 = cycle stamps of one FF chunk
 #if UR_CHAIN_ABL == 4
 #include "tchain_asm_abl4.inc"
 #elif UR_CHAIN_ABL == 5
@@ -68,6 +68,9 @@ struct TChain {
   int lane, wid, h, voff;
   int ti, ntiles, islot, cslot;             // next tile to issue, its ring slot; ring slot of the next tile to consume
   int aoff[4];                              // lane's LDS offsets of the A fragment for the 4 k-steps of a [rows][128 B] block
+#if UR_CHAIN_ABL == 6
+  unsigned long long* dbg = nullptr;        // ablation 6: cycle stamps of one FF chunk (tools/bench_chain.py)
+#endif
 
 #define TC_MFMA_BLOCK(ASM, ...)                                                              \
   do {                                                                                       \
@@ -133,13 +136,13 @@ struct TChain {
   template <bool Z>
   __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[10], const frag_t& b0, const frag_t& b1, const frag_t& b2, const frag_t& b3, unsigned slot) {
     const unsigned a0 = slot + aoff[0], a1 = slot + aoff[1], a2 = slot + aoff[2], a3 = slot + aoff[3];
-    frag_t t0, t1, t2, t3, t4, t5, t6, t7;
+    frag_t t0, t1, t2, t3, t4, t5, t6;
     unsigned so, ld;
     dma_args(so, ld);
 #define TC_GEMM_OPERANDS                                                                                                        \
     : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]),  \
-      "+a"(acc[9]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "+s"(so), "+s"(ld)       \
-    : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs)                                    \
+      "+a"(acc[9]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "+s"(so), "+s"(ld)       \
+    : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs), "s"(wid)                                  \
     : "memory", "scc"
     if constexpr (Z) TC_MFMA_BLOCK(TC_ASM_GEMM_N10_Z, TC_GEMM_OPERANDS);
     else TC_MFMA_BLOCK(TC_ASM_GEMM_N10, TC_GEMM_OPERANDS);
@@ -162,76 +165,78 @@ struct TChain {
   // GEGLU up-projection of 32 hidden units over K = 320: 5 blocks of [32 a rows | 32 g rows][128 B], B fragments xb[0..19]
   __device__ __forceinline__ void ff1_tile(f32x16 (&ag)[2], const frag_t (&xb)[20], unsigned slot) {
     const unsigned a0 = slot + aoff[0], a1 = slot + aoff[1], a2 = slot + aoff[2], a3 = slot + aoff[3];
-    frag_t t0, t1, t2, t3, t4, t5, t6, t7;
+    frag_t t0, t1, t2, t3, t4, t5, t6;
     unsigned so, ld;
     dma_args(so, ld);
     TC_MFMA_BLOCK(TC_ASM_FF1_A,
-                  : "+a"(ag[0]), "+a"(ag[1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7),
+                  : "+a"(ag[0]), "+a"(ag[1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6),
                     "+s"(so), "+s"(ld)
                   : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(xb[4]), "v"(xb[5]), "v"(xb[6]), "v"(xb[7]), "v"(xb[8]), "v"(xb[9]),
-                    "v"(xb[10]), "v"(xb[11]), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs)
+                    "v"(xb[10]), "v"(xb[11]), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs), "s"(wid)
                   : "memory", "scc");
     TC_MFMA_BLOCK(TC_ASM_FF1_B,
-                  : "+a"(ag[0]), "+a"(ag[1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                  : "+a"(ag[0]), "+a"(ag[1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6)
                   : "v"(xb[12]), "v"(xb[13]), "v"(xb[14]), "v"(xb[15]), "v"(xb[16]), "v"(xb[17]), "v"(xb[18]), "v"(xb[19]),
                     "v"(a0), "v"(a1), "v"(a2), "v"(a3)
                   : "memory");
   }
 
   // ---- epilogue vectors (aux area of a tile; asm reads: hipcc must not see LDS reads behind the DMA, see gen_chain_asm.py) ---
-  // the 8 float4 of an FF1 tile for this lane's half-fragment u: ba | bg | colsum a | colsum g (2 float4 each)
-  __device__ __forceinline__ void aux_ff1(unsigned slot, int u, float4 (&q)[8]) const {
-    const unsigned a = slot + TC_WB + 32 * h + 64 * u;
+  // LDS address of the lane's share of a tile's aux area (fragment offsets are immediate operands of the aux blocks)
+  __device__ __forceinline__ unsigned aux_base(unsigned slot) const { return slot + TC_WB + 32 * h; }
+  // the 8 float4 of an FF1 tile for this lane's half-fragment U: ba | bg | colsum a | colsum g (2 float4 each)
+  template <int U>
+  __device__ __forceinline__ void aux_ff1(unsigned slot, float4 (&q)[8]) const {
     asm volatile(TC_ASM_AUX_FF1
                  : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
-                 : "v"(a)
+                 : "v"(aux_base(slot)), "i"(64 * U)
                  : "memory");
   }
-  // 4 half-fragments (2 accumulator fragments from `f0`) of the fp32 vector at float offset `vec` of the aux area:
-  // q[2*i], q[2*i+1] = the lane's 8 values for half-fragment 2*f0 + i
-  __device__ __forceinline__ void aux_vec4(unsigned slot, int vec, int f0, float4 (&q)[8]) const {
-    const unsigned a = slot + TC_WB + (vec + 32 * f0 + 8 * h) * 4;
+  // 4 half-fragments (2 accumulator fragments from F0) of the fp32 vector at float offset VEC of the aux area:
+  // q[2*i], q[2*i+1] = the lane's 8 values for half-fragment 2*F0 + i
+  template <int VEC, int F0>
+  __device__ __forceinline__ void aux_vec4(unsigned slot, float4 (&q)[8]) const {
     asm volatile(TC_ASM_AUX_8
                  : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
-                 : "v"(a)
+                 : "v"(aux_base(slot)), "i"((VEC + 32 * F0) * 4)
                  : "memory");
   }
 
   // cross-attention scores of one head: S^T[96 keys][32 tokens] = K_h (3 fragments of 32 key rows x 64 d at the tile start) . q^T
   __device__ __forceinline__ void att_s(f32x16& s0, f32x16& s1, f32x16& s2, const frag_t& q0, const frag_t& q1, const frag_t& q2, const frag_t& q3, unsigned slot) {
     const unsigned a0 = slot + aoff[0], a1 = slot + aoff[1], a2 = slot + aoff[2], a3 = slot + aoff[3];
-    frag_t t0, t1, t2, t3, t4, t5, t6, t7;
+    frag_t t0, t1, t2, t3, t4, t5, t6;
     unsigned so, ld;
     dma_args(so, ld);
     TC_MFMA_BLOCK(TC_ASM_ATT_S,
-                  : "+a"(s0), "+a"(s1), "+a"(s2), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6),
-                    "=&v"(t7), "+s"(so), "+s"(ld)
-                  : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs)
+                  : "+a"(s0), "+a"(s1), "+a"(s2), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "+s"(so), "+s"(ld)
+                  : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(voff), "s"(rs), "s"(wid)
                   : "memory", "scc");
   }
   // O^T[64 d][32 tokens] = V^T_h (two [64 d rows][128 B] blocks at bytes 12288 / 20480: keys 0-63 | 64-127) . P^T, first 80 keys
   __device__ __forceinline__ void att_pv(f32x16 (&o)[2], const frag_t (&pf)[5], unsigned slot) {
     const unsigned v0 = slot + 12288, v1 = slot + 20480;
     const unsigned a0 = v0 + aoff[0], a1 = v0 + aoff[1], a2 = v0 + aoff[2], a3 = v0 + aoff[3], a4 = v1 + aoff[0];
-    frag_t t0, t1, t2, t3, t4, t5, t6, t7;
+    frag_t t0, t1, t2, t3, t4, t5, t6;
     TC_MFMA_BLOCK(TC_ASM_ATT_PV,
-                  : "+a"(o[0]), "+a"(o[1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                  : "+a"(o[0]), "+a"(o[1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6)
                   : "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4)
                   : "memory");
   }
-  // bias (floats 32f..) and column sums (floats 512 + 32f..) of ONE fragment f: q[0..3] bias (u = 0, 1), q[4..7] column sums
-  __device__ __forceinline__ void aux_bc(unsigned slot, int f, float4 (&q)[8]) const {
-    const unsigned a = slot + TC_WB + (32 * f + 8 * h) * 4;
+  // bias (floats 32 F..) and column sums (floats 512 + 32 F..) of ONE fragment F: q[0..3] bias (u = 0, 1), q[4..7] column sums
+  template <int F>
+  __device__ __forceinline__ void aux_bc(unsigned slot, float4 (&q)[8]) const {
     asm volatile(TC_ASM_AUX_BC8
                  : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
-                 : "v"(a)
+                 : "v"(aux_base(slot)), "i"(128 * F)
                  : "memory");
   }
   // LayerNorm-folded epilogue of ONE accumulator fragment: out[0..1] = 16-bit(rstd * (acc - mean * colsum) + bias'), vectors of
-  // fragment `fa` of the aux area of `slot`
-  __device__ __forceinline__ void ln_pack(const f32x16& acc, unsigned slot, int fa, float mean, float rstd, frag_t& o0, frag_t& o1) const {
+  // fragment FA of the aux area of `slot`
+  template <int FA>
+  __device__ __forceinline__ void ln_pack(const f32x16& acc, unsigned slot, float mean, float rstd, frag_t& o0, frag_t& o1) const {
     float4 q[8];
-    aux_bc(slot, fa, q);
+    aux_bc<FA>(slot, q);
     const float mr = mean * rstd;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -248,22 +253,27 @@ struct TChain {
   // out[2f+u] = 16-bit(acc + bias [+ residual res[2f+u]]) for the 10 fragments of a bias-only stage; `res` may alias `out`
   template <bool RES>
   __device__ __forceinline__ void bias_res_pack(const f32x16 (&acc)[10], unsigned slot, const frag_t (&res)[20], frag_t (&out)[20]) const {
+    bias_res_pair<RES, 0>(acc, slot, res, out);
+    bias_res_pair<RES, 1>(acc, slot, res, out);
+    bias_res_pair<RES, 2>(acc, slot, res, out);
+    bias_res_pair<RES, 3>(acc, slot, res, out);
+    bias_res_pair<RES, 4>(acc, slot, res, out);
+  }
+  template <bool RES, int FP>                               // two fragments at a time: 32 registers of bias values live
+  __device__ __forceinline__ void bias_res_pair(const f32x16 (&acc)[10], unsigned slot, const frag_t (&res)[20], frag_t (&out)[20]) const {
+    float4 q[8];
+    aux_vec4<0, 2 * FP>(slot, q);
 #pragma unroll
-    for (int fp = 0; fp < 5; ++fp) {                     // two fragments at a time: 32 registers of bias values live
-      float4 q[8];
-      aux_vec4(slot, 0, 2 * fp, q);
+    for (int i = 0; i < 4; ++i) {
+      const int f = 2 * FP + (i >> 1), u = i & 1;
+      float r[8], v[8];
+      if constexpr (RES) unpack(res[2 * f + u], r);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int f = 2 * fp + (i >> 1), u = i & 1;
-        float r[8], v[8];
-        if constexpr (RES) unpack(res[2 * f + u], r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = acc[f][8 * u + e] + f4e(q[2 * i + (e >> 2)], e & 3);
-          if constexpr (RES) v[e] += r[e];
-        }
-        out[2 * f + u] = pack(v);
+      for (int e = 0; e < 8; ++e) {
+        v[e] = acc[f][8 * u + e] + f4e(q[2 * i + (e >> 2)], e & 3);
+        if constexpr (RES) v[e] += r[e];
       }
+      out[2 * f + u] = pack(v);
     }
   }
 };
@@ -292,6 +302,23 @@ __device__ __forceinline__ void row_stats(const typename Frag<F16>::type (&x)[KS
   rstd = rsqrtf(q * (1.0f / (16 * KS)) + eps);
 }
 
+// GEGLU epilogue of half-fragment U of an FF1 tile: 16-bit((rstd*(a - mean*ca) + ba) * gelu(rstd*(g - mean*cg) + bg)), 8 hidden units
+template <bool F16, int U>
+__device__ __forceinline__ typename Frag<F16>::type ff1_epilogue(const TChain<F16>& tc, const f32x16 (&ag)[2], unsigned slot, float rstd, float mr) {
+  float4 q[8];                                 // ba | bg | colsum a | colsum g of the lane's 8 channels
+  tc.template aux_ff1<U>(slot, q);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float ba = f4e(q[e >> 2], e & 3), bg = f4e(q[2 + (e >> 2)], e & 3);
+    const float ca = f4e(q[4 + (e >> 2)], e & 3), cg = f4e(q[6 + (e >> 2)], e & 3);
+    const float a = fmaf(rstd, ag[0][8 * U + e], fmaf(-mr, ca, ba));
+    const float g = fmaf(rstd, ag[1][8 * U + e], fmaf(-mr, cg, bg));
+    v[e] = UR_CHAIN_ABL == 3 ? a * g : a * gelu_f(g);
+  }
+  return TChain<F16>::pack(v);
+}
+
 // FeedForward(GEGLU) over the LayerNorm of xb (raw fragments; LayerNorm folded: mean / rstd given): acc += W2 . GEGLU(...) (no b2);
 // the caller zeroes acc (ONE asm instance of the FF2 phase in the loop: with a second, zero-initialising one for the first chunk
 // hipcc's register allocation of the whole kernel degraded to ~100 spilled registers).
@@ -304,31 +331,36 @@ __device__ __forceinline__ unsigned ff_stage(TChain<F16>& tc, f32x16 (&acc)[10],
   typedef typename Frag<F16>::type frag_t;
   const float mr = mean * rstd;
   unsigned last = 0;
+#if UR_CHAIN_ABL == 6
+  unsigned long long ts[12];
+#define TC_TS(i) do { if (c == 10) ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TC_TS(i) do {} while (0)
+#endif
   for (int c = 0; c < nchunk; ++c) {
     frag_t hid[4];
+    TC_TS(0);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const unsigned slot = tc.acquire();
+      TC_TS(1 + 3 * half);
       tc.ff1_tile(ag, xb, slot);               // (zeroes ag: its first MFMAs take C = 0)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        float4 q[8];                           // ba | bg | colsum a | colsum g of the lane's 8 channels of half-fragment u
-        tc.aux_ff1(slot, u, q);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float ba = f4e(q[e >> 2], e & 3), bg = f4e(q[2 + (e >> 2)], e & 3);
-          const float ca = f4e(q[4 + (e >> 2)], e & 3), cg = f4e(q[6 + (e >> 2)], e & 3);
-          const float a = fmaf(rstd, ag[0][8 * u + e], fmaf(-mr, ca, ba));       // rstd*(acc - mean*colsum) + bias
-          const float g = fmaf(rstd, ag[1][8 * u + e], fmaf(-mr, cg, bg));
-          v[e] = UR_CHAIN_ABL == 3 ? a * g : a * gelu_f(g);
-        }
-        hid[half * 2 + u] = tc.pack(v);
-      }
+      TC_TS(2 + 3 * half);
+      hid[half * 2] = ff1_epilogue<F16, 0>(tc, ag, slot, rstd, mr);
+      __builtin_amdgcn_sched_barrier(0);       // (one half-fragment's temporaries at a time: interleaved, the two spill)
+      hid[half * 2 + 1] = ff1_epilogue<F16, 1>(tc, ag, slot, rstd, mr);
+      __builtin_amdgcn_sched_barrier(0);
+      TC_TS(3 + 3 * half);
     }
     last = tc.acquire();
+    TC_TS(7);
     tc.template gemm_tile<false>(acc, hid[0], hid[1], hid[2], hid[3], last);     // (acc starts at zero: see the callers)
+    TC_TS(8);
   }
+#if UR_CHAIN_ABL == 6
+  if (tc.dbg && blockIdx.x == 17 && tc.lane == 0)
+    for (int i = 0; i < 9; ++i) tc.dbg[tc.wid * 16 + i] = ts[i];
+#endif
   return last;
 }
 
@@ -361,6 +393,9 @@ __global__ __launch_bounds__(256, 1) void tchain_mlp_kernel(const MlpP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TChain<F16> tc;
   tc.init(smem, p.stream, p.ntiles);
+#if UR_CHAIN_ABL == 6
+  tc.dbg = reinterpret_cast<unsigned long long*>(p.y + (long long)(p.T - 128) * p.ldy);      // (timing build: stamps land in the last rows of y)
+#endif
   const long long tok = (long long)blockIdx.x * TC_TOK + tc.wid * 32 + (tc.lane & 31);
   frag_t xb[20];
   load_frags<F16>(p.x, tok, p.ldx, tc.h, xb);
@@ -374,6 +409,9 @@ __global__ __launch_bounds__(256, 1) void tchain_mlp_kernel(const MlpP p) {
 #pragma unroll
   for (int s = 0; s < 20; ++s) asm volatile("" : "+v"(xb[s]));      // opaque: hipcc would otherwise keep the 160 fp32 values row_stats unpacked alive (in scratch) across the loop
   tc.template bias_res_pack<true>(acc, last, xb, xb);
+#if UR_CHAIN_ABL == 6
+  if (blockIdx.x != gridDim.x - 1)               // (timing build: the stamps live in the last workgroup's rows)
+#endif
   store_frags<F16>(p.y, tok, p.ldy, tc.h, xb);
   TC_WAIT(0);                                    // no LDS-DMA may outlive the workgroup
 }
@@ -404,6 +442,22 @@ __device__ __forceinline__ void launder(typename Frag<F16>::type (&x)[20]) {
   // the fragments' next unpack, many phases later
 #pragma unroll
   for (int s = 0; s < 20; ++s) asm volatile("" : "+v"(x[s]));
+}
+
+// HEAD: LayerNorm-folded epilogue of fragment F of a q / k / v stage
+template <bool F16, int F>
+__device__ __forceinline__ void head_out(const TChain<F16>& tc, const f32x16 (&acc)[10], unsigned slot, float mean, float rstd, int part,
+                                         uint16_t* op, typename Frag<F16>::type (&xb)[20]) {
+  typedef typename Frag<F16>::type frag_t;
+  frag_t o0, o1;
+  tc.template ln_pack<F>(acc[F], slot, mean, rstd, o0, o1);
+  if (part < 2) {                                                // q, k: straight out (two 16-byte stores per fragment)
+    *reinterpret_cast<frag_t*>(op + 32 * F) = o0;
+    *reinterpret_cast<frag_t*>(op + 32 * F + 16) = o1;
+  } else {                                                       // v: h0's fragments are dead now - keep v in their registers
+    xb[2 * F] = o0;
+    xb[2 * F + 1] = o1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -460,18 +514,16 @@ __global__ __launch_bounds__(256, 1) void tchain_head_kernel(const HeadP p) {
   for (int part = 0; part < 3; ++part) {
     slot = tc.template gemm_stage<20>(acc, xb);
     uint16_t* op = (part == 0 ? p.q : p.k) + token_again() * C + 8 * tc.h;
-#pragma unroll
-    for (int f = 0; f < 10; ++f) {
-      frag_t o0, o1;
-      tc.ln_pack(acc[f], slot, f, mean, rstd, o0, o1);
-      if (part < 2) {                                                // q, k: straight out (two 16-byte stores per fragment)
-        *reinterpret_cast<frag_t*>(op + 32 * f) = o0;
-        *reinterpret_cast<frag_t*>(op + 32 * f + 16) = o1;
-      } else {                                                       // v: h0's fragments are dead now - keep v in their registers
-        xb[2 * f] = o0;
-        xb[2 * f + 1] = o1;
-      }
-    }
+    head_out<F16, 0>(tc, acc, slot, mean, rstd, part, op, xb);
+    head_out<F16, 1>(tc, acc, slot, mean, rstd, part, op, xb);
+    head_out<F16, 2>(tc, acc, slot, mean, rstd, part, op, xb);
+    head_out<F16, 3>(tc, acc, slot, mean, rstd, part, op, xb);
+    head_out<F16, 4>(tc, acc, slot, mean, rstd, part, op, xb);
+    head_out<F16, 5>(tc, acc, slot, mean, rstd, part, op, xb);
+    head_out<F16, 6>(tc, acc, slot, mean, rstd, part, op, xb);
+    head_out<F16, 7>(tc, acc, slot, mean, rstd, part, op, xb);
+    head_out<F16, 8>(tc, acc, slot, mean, rstd, part, op, xb);
+    head_out<F16, 9>(tc, acc, slot, mean, rstd, part, op, xb);
   }
   // v^T: transpose this wave's [32 tokens][320 channels] through LDS (the ring is free: the stream has ended)
   tc.drain();
@@ -553,19 +605,21 @@ __global__ __launch_bounds__(256, 1) void tchain_tail_kernel(const TailP p) {
     slot = tc.acquire();
     tc.ff1_tile(ag, hb, slot);
     frag_t qf[4];
-    tc.ln_pack(ag[0], slot, 0, mean, rstd, qf[0], qf[1]);
-    tc.ln_pack(ag[1], slot, 1, mean, rstd, qf[2], qf[3]);
+    tc.template ln_pack<0>(ag[0], slot, mean, rstd, qf[0], qf[1]);
+    tc.template ln_pack<1>(ag[1], slot, mean, rstd, qf[2], qf[3]);
     slot = tc.acquire();
     tc.att_s(ag[0], ag[1], sc2[0], qf[0], qf[1], qf[2], qf[3], slot);
     // softmax over the keys: the lane holds 48 of its token's 96 scores (key = 32 kf + 16 (r >> 3) + 8 h + (r & 7)), the other
     // half's lane the rest.  Two passes over the accumulator registers (maximum, then exp2 + sum + pack): no 48-float copy.
+    int lim = p.tk - 8 * tc.h;                        // key index (without the lane half's + 8h) below which a key is real
+    asm volatile("" : "+v"(lim));                     // opaque per head: hipcc otherwise hoists all 88 key comparisons of all heads to kernel entry (as 88 live masks)
     float mx = -INFINITY;
 #pragma unroll
     for (int kf = 0; kf < 3; ++kf)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = 32 * kf + 16 * (r >> 3) + 8 * tc.h + (r & 7);
-        mx = fmaxf(mx, key < p.tk ? (kf < 2 ? ag[kf & 1][r] : sc2[0][r]) : -INFINITY);
+        const int key = 32 * kf + 16 * (r >> 3) + (r & 7);
+        mx = fmaxf(mx, key < lim ? (kf < 2 ? ag[kf & 1][r] : sc2[0][r]) : -INFINITY);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mc = mx * p.scale_log2e;
@@ -576,9 +630,9 @@ __global__ __launch_bounds__(256, 1) void tchain_tail_kernel(const TailP p) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int key = 16 * ks + 8 * tc.h + e;
+        const int key = 16 * ks + e;
         const float sv = ks < 4 ? ag[(ks >> 1) & 1][8 * (ks & 1) + e] : sc2[0][e];
-        v[e] = key < p.tk ? __builtin_amdgcn_exp2f(fmaf(sv, p.scale_log2e, -mc)) : 0.f;
+        v[e] = key < lim ? __builtin_amdgcn_exp2f(fmaf(sv, p.scale_log2e, -mc)) : 0.f;
         l += v[e];
       }
       pf[ks] = tc.pack(v);

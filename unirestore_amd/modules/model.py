@@ -27,6 +27,14 @@ stablesr_config = dict(in_channels=4, model_channels=256, out_channels=256, num_
                        down_block_types=("AttnDownBlock2D",) * 3 + ("DownBlock2D",), mid_block_type="UNetMidBlock2D")
 
 
+def _use_dtype(module):
+    """Re-assert the 16-bit compute type of the DiffUIE that owns `module` (the op front end keeps it in a process global that
+    constructing / calling another model may have changed).  Stand-alone sub-modules keep whatever type is current."""
+    dt = module.__dict__.get("_ur_dtype")
+    if dt is not None:
+        ops.set_dtype(dt)
+
+
 def _resnets(module):
     return [m for m in module.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
 
@@ -101,6 +109,7 @@ class Controller(nn.Module):
 
     def forward(self, x, timesteps, encoder_hidden_states=None):
         """Reference signature: x (B,4,h,w) fp32 NCHW, timesteps (1,) or (B,) -> {width: (B,256,h',w') fp32}."""
+        _use_dtype(self)
         ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
         if len(set(ts)) != 1:
             raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
@@ -204,6 +213,7 @@ class ControlledUNet(nn.Module):
 
     def forward(self, sample, control, timesteps):
         """Reference signature (base_model.py:211-245): NCHW fp32 in, eps NCHW fp32 out."""
+        _use_dtype(self)
         ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
         if len(set(ts)) != 1:
             raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
@@ -284,6 +294,7 @@ class SkipConnectedAutoEncoder(nn.Module):
 
     # ---- reference signatures ---------------------------------------------------------------------------------
     def encode(self, images, enable_fr: bool = False, noise=None):
+        _use_dtype(self)
         images = images.to(DEV).float()
         b, _, hh, ww = images.shape
         if noise is None:
@@ -292,6 +303,7 @@ class SkipConnectedAutoEncoder(nn.Module):
         return ops.nhwc_to_nchw(z, c=self.vae.latent_channels), [ops.nhwc_to_nchw(r) for r in res]
 
     def decode(self, latents, res_samples, task: str):
+        _use_dtype(self)
         z = ops.nchw_to_nhwc(latents.to(DEV)).float()
         return self.decode_run(z.contiguous(), [ops.nchw_to_nhwc(r.to(DEV)) for r in res_samples], task)
 
@@ -335,6 +347,14 @@ class DiffUIE(nn.Module):
             self.timesteps = schedule.ddim_timesteps(self.num_inference_steps)       # host int64, bit-exact
             self._tables_ready = False
             self._table_epochs = None
+        self._own_dtype()
+
+    def _own_dtype(self):
+        """The operator-level entry points of the sub-modules (ae.encode / decode, Controller.forward, ControlledUNet.forward) run
+        in THIS model's 16-bit type, whatever another model set in between."""
+        for m in (self.ae, getattr(self, "controller", None), getattr(self, "base_model", None)):
+            if m is not None:
+                m.__dict__["_ur_dtype"] = self.dtype
 
     def set_num_inference_steps(self, n: int):
         """Change the DDIM schedule length (`cnet.num_inference_steps`, unifie.py:70-75): tables and graphs are rebuilt lazily."""
@@ -346,6 +366,7 @@ class DiffUIE(nn.Module):
     def set_dtype(self, dtype):
         """Switch the 16-bit compute type; packed weights are kept per type, captured graphs are dropped."""
         self.dtype = ops.set_dtype(dtype)
+        self._own_dtype()
         self._graphs.clear()
         return self
 

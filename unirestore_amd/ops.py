@@ -311,6 +311,8 @@ def bmm_nt(a: torch.Tensor, bmat: torch.Tensor, *, out_f32=False, out_scale=1.0)
     """Batched C[b] = A[b] @ B[b]^T with A:[B,M,K], B:[B,N,K] bf16 (last dim contiguous; row strides free)."""
     B, M, K = a.shape
     N = bmat.shape[1]
+    if a.dtype != bmat.dtype or a.dtype not in (BF16, F16):
+        raise ValueError(f"bmm_nt: both operands must share one 16-bit type, got {a.dtype} and {bmat.dtype}")
     assert a.stride(2) == 1 and bmat.stride(2) == 1 and K % 8 == 0 and N % 4 == 0
     out = torch.empty((B, M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
     d = ConvDesc()
@@ -405,6 +407,8 @@ def attention(q, k, vt, heads: int, head_dim: int, tq: int, tk: int, scale: floa
               batch: int, out=None):
     """q:[B,Tq,ldq] k:[B?,Tk,ldk] vt:[B?,H*D,ldvt] (raw tensors; strides given explicitly) -> o [B,Tq,H*D]."""
     c = heads * head_dim
+    if not (q.dtype == k.dtype == vt.dtype) or q.dtype not in (BF16, F16):
+        raise ValueError(f"attention: q, k, v^T must share one 16-bit type, got {q.dtype}, {k.dtype}, {vt.dtype}")
     out = torch.empty((batch, tq, c), dtype=q.dtype, device=q.device) if out is None else out
     check(lib.ur_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, tq, tk, head_dim,
                                ldq, ldk, vt.shape[-1], c, bs_q, bs_k, bs_vt, tq * c, scale, _dt(q), _stream()))

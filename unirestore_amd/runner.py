@@ -39,10 +39,18 @@ def validation_step(model, lq: torch.Tensor, hq: torch.Tensor = None, task: str 
     return forward(model, inputs, task, quantize=True), hq
 
 
+def psnr_per_image(pred: torch.Tensor, target: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """PSNR of every image of the batch (fp64 [N]): skimage's peak_signal_noise_ratio per sample - what the reference's SKPSNR sums
+    before dividing by the image count (eval_image_restoration.py:266-278)."""
+    d = (pred.double().cpu() - target.double().cpu()) ** 2
+    mse = d.reshape(d.shape[0], -1).mean(dim=1)
+    return 10.0 * torch.log10(data_range ** 2 / mse)
+
+
 def psnr(pred: torch.Tensor, target: torch.Tensor, data_range: float = 1.0) -> float:
-    """Full-reference PSNR over the batch (what `val_lq/psnr` reports, eval_image_restoration.py:102-104,181)."""
-    mse = torch.mean((pred.double().cpu() - target.double().cpu()) ** 2)
-    return float(10.0 * torch.log10(data_range ** 2 / mse))
+    """`val_lq/psnr` of a batch: the MEAN OF THE PER-IMAGE PSNRs (not the PSNR of the batch-mean MSE: the two differ as soon as
+    the images differ; eval_image_restoration.py:102-104,181,266-278)."""
+    return float(psnr_per_image(pred, target, data_range).mean())
 
 
 def ssim(pred: torch.Tensor, target: torch.Tensor, data_range: float = 1.0, win: int = 7) -> float:
@@ -82,14 +90,15 @@ class LitUniFIE:
     def forward(self, inputs: Sequence[torch.Tensor], task: str, quantize: bool = False) -> List[torch.Tensor]:
         return forward(self.model, inputs, task, quantize=quantize)
 
-    def validation_step(self, batch, eval_types: Sequence[str] = ("lq",)):
-        lq, hq, _gt, _fname, task = batch
-        preds, hq_c = validation_step(self.model, lq, hq, task=task if task in self.task_dict else "ir",
-                                      need_crop=self.need_crop, eval_types=eval_types)
-        if hq_c is not None and self.eval_mode in ("FR", "ALL") and preds[-1].shape == (crop_tensor(hq) if self.need_crop else hq).shape:
+    def validation_step(self, batch, eval_types: Sequence[str] = ("lq",), metrics: bool = True):
+        lq, hq, _gt, _fname, _task = batch
+        # the IR evaluator always restores with the "ir" prompt (eval_image_restoration.py:70: self.forward(inputs, 'ir')), whatever
+        # task tag the batch carries; task-driven decoding belongs to the downstream (MTL) evaluators, which are out of scope
+        preds, hq_c = validation_step(self.model, lq, hq, task="ir", need_crop=self.need_crop, eval_types=eval_types)
+        if metrics and hq_c is not None and self.eval_mode in ("FR", "ALL") and preds[-1].shape == (crop_tensor(hq) if self.need_crop else hq).shape:
             tgt = crop_tensor(hq) if self.need_crop else hq
             n = preds[-1].shape[0]
-            self.totals["psnr"] += psnr(preds[-1], tgt) * n
+            self.totals["psnr"] += float(psnr_per_image(preds[-1], tgt).sum())          # sum over images (SKPSNR state)
             self.totals["ssim"] += ssim(preds[-1], tgt) * n
             self.totals["images"] += n
         return preds
@@ -98,7 +107,7 @@ class LitUniFIE:
     @torch.no_grad()
     def fr_training_fwd(self, hq, lq):
         """AE encoder (+CFRM on the degraded input): (h0, h0_mids, l0, l0_mids) - engine_unifie.py:135-148."""
-        h0, h0_mids = self.model.ae.encode(hq, enable_fr=False, noise=self._noise(hq))
+        h0, h0_mids = self.model.ae.encode(hq, enable_fr=False, noise=self._noise(hq))        # (ae.encode re-asserts the model's dtype)
         l0, l0_mids = self.model.ae.encode(lq, enable_fr=bool(self.model_kwargs.get("frenc")), noise=self._noise(lq))
         return h0, h0_mids, l0, l0_mids
 
@@ -132,6 +141,15 @@ class LitUniFIE:
             return None
         g = torch.Generator().manual_seed(self.noise_seed + int(img.shape[-1]))
         return torch.randn(img.shape[0], self.model.ae.vae.latent_channels, img.shape[-2] // 8, img.shape[-1] // 8, generator=g)
+
+    def update_metrics(self, preds: torch.Tensor, hq: torch.Tensor):
+        """Metric states for one batch of restored images vs their clean targets (for callers that time the forward separately)."""
+        tgt = crop_tensor(hq) if self.need_crop else hq
+        if self.eval_mode in ("FR", "ALL") and preds.shape == tgt.shape:
+            n = preds.shape[0]
+            self.totals["psnr"] += float(psnr_per_image(preds, tgt).sum())
+            self.totals["ssim"] += ssim(preds, tgt) * n
+            self.totals["images"] += n
 
     def metrics(self) -> dict:
         n = max(self.totals["images"], 1)
