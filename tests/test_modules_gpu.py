@@ -26,37 +26,74 @@ def _copy(dst, src_state):
     return dst
 
 
+@pytest.fixture(params=["bf16", "fp16"])
+def gdt(request):
+    """The reference-pinned golden fixtures run in BOTH 16-bit types, selected explicitly (no dependence on test order)."""
+    from unirestore_amd import ops
+    ops.set_dtype(request.param)
+    yield request.param
+    ops.set_dtype("bf16")
+
+
+# golden fixtures: outputs of the reference classes (tools/gen_golden.py); tolerance per type = 16-bit operands + stored
+# activations through a 3-5 layer adapter (measured r3 on MI355X: bf16 2.1-5.3e-3, fp16 2.7-6.8e-4; CFRM = 11 blocks deep: 9.6e-3 / 1.2e-3)
+GTOL = {"bf16": 8e-3, "fp16": 1.1e-3}
+GTOL_CFRM = {"bf16": 1.5e-2, "fp16": 2e-3}
+
+
 @pytest.mark.parametrize("name", golden_names("csce"))
-def test_csce_golden(M, name):
+def test_csce_golden(M, gdt, name):
     w, i, o = load_golden(name)
     m = M.CSCEAdapter(w["proj.weight"].shape[0], w["tuner.0.weight"].shape[0], w["proj.weight"].shape[1])
     m.load_state_dict(w)
-    assert rel_l2(m(i["x"], i["condition"]).cpu(), o["y"]) < 8e-3
+    assert rel_l2(m(i["x"], i["condition"]).cpu(), o["y"]) < GTOL[gdt]
 
 
 @pytest.mark.parametrize("name", golden_names("tfa"))
-def test_tfa_golden(M, name):
+def test_tfa_golden(M, gdt, name):
     w, i, o = load_golden(name)
     cs, co = w["t_gate1.weight"].shape[1], w["conv_out.weight"].shape[0]
     t = w["out_gate.0.weight"].shape[1] // cs
     m = M.TaskFeatureAdapter(co, cs, t, "prompt_trans.0.weight" not in w)
     m.load_state_dict(w)
     x, c = m(i["x"], i["skip"], i["condition"])
-    assert rel_l2(x.cpu(), o["x"]) < 8e-3
+    assert rel_l2(x.cpu(), o["x"]) < GTOL[gdt]
     if "condition" in o:
-        assert rel_l2(c.cpu(), o["condition"]) < 8e-3
+        assert rel_l2(c.cpu(), o["condition"]) < GTOL[gdt]
     else:
         assert c is None
 
 
-@pytest.mark.parametrize("name", ["cfrm_1"])       # cfrm_0 has c=16 (< the 32-channel granularity of the gate epilogue)
-def test_cfrm_golden(M, name):
+@pytest.mark.parametrize("name", ["cfrm_1"])
+def test_cfrm_golden(M, gdt, name):
     w, i, o = load_golden(name)
     c = w["0.conv1.weight"].shape[1]
     n = max(int(k.split(".")[0]) for k in w)
     m = M.cfrm_blocks((c,), (n,))[0]
     m.load_state_dict(w)
-    assert rel_l2(m(i["x"]).cpu(), o["y"]) < 1.5e-2
+    assert rel_l2(m(i["x"]).cpu(), o["y"]) < GTOL_CFRM[gdt]
+
+
+def test_cfrm_narrow_width_is_refused_not_miscomputed(M):
+    """cfrm_0 (C = 16): SimpleGate needs whole 32-row (a | g) blocks in the GEMM epilogue.  The production widths are 128 / 256 /
+    512; a narrower block is REFUSED with UR_E_UNSUPPORTED - by the packer and by the C entry point - never computed wrongly."""
+    import ctypes
+    from unirestore_amd import capi, ops
+    w, i, o = load_golden("cfrm_0")
+    c = w["0.conv1.weight"].shape[1]
+    assert c == 16
+    n = max(int(k.split(".")[0]) for k in w)
+    m = M.cfrm_blocks((c,), (n,))[0]
+    m.load_state_dict(w)
+    with pytest.raises(NotImplementedError, match="UR_E_UNSUPPORTED"):
+        m(i["x"])
+    # the C ABI itself: a pair activation over 32 GEMM columns (16 outputs)
+    x = torch.zeros(64, 16, dtype=torch.bfloat16, device="cuda")
+    wt = torch.zeros(32, 16, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(64, 16, dtype=torch.bfloat16, device="cuda")
+    rc = capi.lib.ur_gemm_bias_act(x.data_ptr(), wt.data_ptr(), None, None, y.data_ptr(), 64, 32, 16, 16, 16, 16, 0, capi.UR_ACT_GATE,
+                                   None, 0, capi.UR_DT_BF16, torch.cuda.current_stream().cuda_stream)
+    assert rc == capi.UR_E_UNSUPPORTED and b"pair" in capi.lib.ur_last_error()
 
 
 def _pair(M, seed=0, steps=2, dtype="bf16", kw=None):
@@ -176,12 +213,12 @@ def test_runner_validation_step_quantised(M):
         p(small, "ir", noise=(nz[0][..., :-1], nz[1]))
 
 
-def test_spade_golden(M):
+def test_spade_golden(M, gdt):
     """SPADE (spade.py:29-71) against the vector generated from the reference class."""
     w, i, o = load_golden("spade_0")
     m = M.SPADE(w["mlp_gamma.weight"].shape[0], w["mlp_shared.0.weight"].shape[1])
     m.load_state_dict(w)
-    assert rel_l2(m(i["x"], i["segmap"]).cpu(), o["y"]) < 8e-3
+    assert rel_l2(m(i["x"], i["segmap"]).cpu(), o["y"]) < GTOL[gdt]
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -342,3 +379,33 @@ def test_training_step_forward_halves(M, dtype):
     lit.noise_seed = 3                                      # the wrapper itself: reproducible, shapes as the reference's tuple
     a, b = lit.fr_training_fwd(hq, lq), lit.fr_training_fwd(hq, lq)
     assert len(a) == 4 and len(a[1]) == 3 and all(torch.equal(x, y) for x, y in zip(a[1] + a[3], b[1] + b[3]))
+
+
+def test_submodule_load_state_dict_needs_no_refresh(M):
+    """The reference's engine loads SUB-module state dicts (engine_unifie.py:58,75,81,114,125) and then calls forward: load hooks on
+    every module mark the packed device copies / schedule tables / graphs stale - no `refresh()` at the integration site."""
+    o, p = _pair(M, 5, steps=1, dtype="fp16")
+    p.use_graph = True
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(1, 3, 64, 64, generator=g)
+    noise = (torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g))
+    y0 = p(img, "ir", noise=noise).cpu()
+    o2 = randomise_(type(o)(**model_kwargs(1), **TINY).eval(), 9)          # different weights
+    p.controller.load_state_dict(o2.controller.state_dict())                                       # :75
+    p.base_model.csc_editors.load_state_dict(o2.base_model.csc_editors.state_dict())               # :81
+    p.ae.vae.encoder.fr_blocks.load_state_dict(o2.ae.vae.encoder.fr_blocks.state_dict())           # :58
+    p.ae.vae.decoder.task_editors.load_state_dict(o2.ae.vae.decoder.task_editors.state_dict())     # :125
+    p.ae.vae.decoder.task_prompts.load_state_dict(o2.ae.vae.decoder.task_prompts.state_dict(), strict=False)   # :114
+    mixed = type(o)(**model_kwargs(1), **TINY).eval()
+    mixed.load_state_dict(p.state_dict())
+    ref = mixed(img, "ir", noise=noise)
+    y1 = p(img, "ir", noise=noise).cpu()                     # NO p.refresh()
+    assert rel_l2(y1, ref) < TOL["fp16"]["fwd_img"] * 1.5
+    assert rel_l2(y1, y0) > 10 * TOL["fp16"]["fwd_img"]       # the new weights were really used
+    # operator-level entry of a sub-module picks its new weights up as well
+    p.controller.load_state_dict(o.controller.state_dict())
+    z = torch.randn(1, 4, 16, 16, generator=g)
+    c_ref = o.controller(z, torch.tensor([999]))
+    c_new = p.controller(z, torch.tensor([999]))
+    for k in c_ref:
+        assert rel_l2(c_new[k].cpu(), c_ref[k]) < TOL["fp16"]["ctrl"] * 1.5

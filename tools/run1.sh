@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-UR_CHAIN_STAMPS=1 UR_LIB=$PWD/unirestore_amd/ab/lib_abl6.so python tools/bench_chain.py 2>&1 | tail -6
+timeout 1500 python -m pytest tests/test_exports_gpu.py tests/test_checkpoint_gpu.py tests/test_modules_gpu.py -x -q -m gpu 2>&1 | tail -15

@@ -186,7 +186,8 @@ static int conv_impl(const ur_conv_desc* d, ur_stream_t stream, int dry, ur_conv
   UR_REQUIRE(d->y || d->yt || d->gn_part, "no output requested");
   UR_REQUIRE_DT(d->dtype);
   const bool pair = d->act == UR_ACT_GEGLU || d->act == UR_ACT_GATE;
-  UR_REQUIRE(!pair || d->Cout % 64 == 0, "pair activations need Cout%64==0 (32-row a|g interleave)");
+  if (pair && d->Cout % 64 != 0)     // (production widths are 128 / 256 / 512 output channels; refused, never computed wrongly)
+    return ur::fail(UR_E_UNSUPPORTED, "ur_conv2d_nhwc: pair activations (GEGLU / SimpleGate) need Cout % 64 == 0 (32-row a|g interleave)");
   UR_REQUIRE(!d->y || (d->out_f32 ? d->ldy % 4 == 0 : d->ldy % 4 == 0), "ldy%4");
   UR_REQUIRE(!d->residual || d->ldr % 4 == 0, "ldr%4");
   UR_REQUIRE(!d->yt || (d->t_rows > 0 && d->n_split % 4 == 0 && !pair), "bad transposed-output spec");

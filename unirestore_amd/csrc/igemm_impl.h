@@ -358,7 +358,7 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
   }
   if (p.row_stats) {
     // per-row (sum, sum of squares) over this tile's columns of the bf16 values just produced: the LayerNorm statistics
-    // of the consumer GEMM.  NT/BM threads share a row; partials meet through float atomics (one pair per row per N tile).
+    // of the consumer GEMM.  NT/BM threads share a row and meet through wave shuffles; one plain store per row into this N tile's plane.
     constexpr int TPR = NT / BM >= 1 ? NT / BM : 1;
     const int r = threadIdx.x / TPR, part = threadIdx.x % TPR;
     if (r < BM) {
@@ -701,8 +701,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const ConvK p) 
 
 // Split-K reduce that also leaves the GroupNorm statistics of what it writes (the 16x16 / 8x8 levels: every 3x3 conv
 // there is split-K, and each used to be followed by a separate statistics pass).  Block = 16 column quads x 16 row
-// lanes over 64 consecutive rows of ONE image (host guarantees OHW % 64 == 0); column sums stay in registers, the
-// row lanes meet in LDS, then one fp64 atomic per (column, moment) per block.
+// lanes over 16 * RI consecutive rows of ONE image (host guarantees OHW % (16 * RI) == 0); column sums stay in registers, the
+// row lanes meet in LDS and are added in row-lane order; one plain store per (column, moment) into the block's own slot of the partial plane.
 template <int RI, bool F16>   // rows per block = 16 * RI (one image: host checks OHW % (16 * RI) == 0)
 __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
   __shared__ float red[16][16][9];

@@ -9,6 +9,7 @@ MI355X-first differences (results unchanged): NHWC bf16 activations, per-schedul
 into conv biases, constant cross-attention K/V computed once, the whole forward replayed as one hipGraph.
 """
 import os
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -30,6 +31,10 @@ stablesr_config = dict(in_channels=4, model_channels=256, out_channels=256, num_
 def _use_dtype(module):
     """Re-assert the 16-bit compute type of the DiffUIE that owns `module` (the op front end keeps it in a process global that
     constructing / calling another model may have changed).  Stand-alone sub-modules keep whatever type is current."""
+    owner = module.__dict__.get("_ur_owner")
+    owner = owner() if owner is not None else None
+    if owner is not None and owner.__dict__.get("_stale"):       # some load_state_dict ran anywhere in the owner's tree
+        owner.refresh()
     dt = module.__dict__.get("_ur_dtype")
     if dt is not None:
         ops.set_dtype(dt)
@@ -172,26 +177,12 @@ class ControlledUNet(nn.Module):
             if blk.downsamplers is not None:
                 h = blk.downsamplers[0].run(h)
                 skips.append(h)
-        # SC-Tuner (base_model.py:233-238).  The adapters only need the skips and the control features, so they run on a side
-        # stream (a parallel branch of the captured graph) in the order the up path consumes them: the large 64x64-level
-        # adapter GEMMs overlap with the mid block / low-resolution up blocks, whose kernels leave most CUs idle.
-        raw, ready = skips, [None] * len(skips)
+        # SC-Tuner (base_model.py:233-238): every skip is edited under the control feature of its resolution.  (A parallel graph
+        # branch for the adapters was measured in round 2 - no gain once the GEMM ring race was fixed - and removed in round 3.)
+        raw = skips
         if sp is not None:                                  # SPADE control: no skip editors (base_model.py:233 hasattr check)
             h = u.mid_block.run(h, step=step, ctx=ctx, control=sp)
             edited = raw
-        elif nnmod.SIDE_STREAM:
-            main, side = torch.cuda.current_stream(), nnmod.side_stream()
-            fork = torch.cuda.Event()
-            fork.record(main)
-            edited = [None] * len(raw)
-            with torch.cuda.stream(side):
-                side.wait_event(fork)
-                for idx in reversed(range(len(raw))):
-                    cond = control[raw[idx].shape[2]]
-                    edited[idx] = self.csc_editors[idx].run(raw[idx], cond)
-                    ready[idx] = torch.cuda.Event()
-                    ready[idx].record(side)
-            h = u.mid_block.run(h, step=step, ctx=ctx)
         else:
             h = u.mid_block.run(h, step=step, ctx=ctx)
             edited = [ed.run(s, control[s.shape[2]]) for ed, s in zip(self.csc_editors, raw)]
@@ -199,15 +190,11 @@ class ControlledUNet(nn.Module):
         for blk in u.up_blocks:
             for i, res in enumerate(blk.resnets):
                 idx -= 1
-                if ready[idx] is not None:
-                    torch.cuda.current_stream().wait_event(ready[idx])
                 h = res.run(h, x2=edited[idx], step=step, control=sp)                           # virtual torch.cat
                 if blk.attn_kind == "cross":
                     h = blk.attentions[i].run(h, ctx)
             if blk.upsamplers is not None:
                 h = blk.upsamplers[0].run(h)
-        # `raw` / `edited` stay referenced until here: memory handed out on one stream and read on the other must not be
-        # recycled while the other branch may still be using it
         h = u.conv_norm_out.run(h, silu=True)
         return ops.conv(h, u.conv_out.packed(), out_f32=True)
 
@@ -348,6 +335,7 @@ class DiffUIE(nn.Module):
             self._tables_ready = False
             self._table_epochs = None
         self._own_dtype()
+        self._arm_load_hooks()
 
     def _own_dtype(self):
         """The operator-level entry points of the sub-modules (ae.encode / decode, Controller.forward, ControlledUNet.forward) run
@@ -355,6 +343,20 @@ class DiffUIE(nn.Module):
         for m in (self.ae, getattr(self, "controller", None), getattr(self, "base_model", None)):
             if m is not None:
                 m.__dict__["_ur_dtype"] = self.dtype
+                m.__dict__["_ur_owner"] = weakref.ref(self)
+
+    def _arm_load_hooks(self):
+        """Every module of the tree reports a finished `load_state_dict` (the reference's engine loads SUB-module state dicts:
+        engine_unifie.py:58,75,81,114,125): the packed device copies, schedule tables and captured graphs derived from the fp32
+        masters are then rebuilt before the next use - no `refresh()` call is needed at the integration site."""
+        ref = weakref.ref(self)
+
+        def loaded(_module, _incompatible):
+            o = ref()
+            if o is not None:
+                o.__dict__["_stale"] = True
+        for m in self.modules():
+            m.register_load_state_dict_post_hook(loaded)
 
     def set_num_inference_steps(self, n: int):
         """Change the DDIM schedule length (`cnet.num_inference_steps`, unifie.py:70-75): tables and graphs are rebuilt lazily."""
@@ -381,8 +383,11 @@ class DiffUIE(nn.Module):
         invalidate_packed(self)
         self._tables_ready = False
         self._graphs.clear()
+        self.__dict__["_stale"] = False
 
     def _prepare(self):
+        if self.__dict__.get("_stale"):
+            self.refresh()
         ops.set_dtype(self.dtype)
         if not self.control_type:
             return
@@ -399,6 +404,8 @@ class DiffUIE(nn.Module):
 
     # ---- reference helper signatures ------------------------------------------------------------------------------
     def diffuse(self, latents, timesteps=None, noise=None):
+        if self.__dict__.get("_stale"):
+            self.refresh()
         ops.set_dtype(self.dtype)
         latents = latents.to(DEV).float()
         if timesteps is None:
@@ -499,6 +506,8 @@ class DiffUIE(nn.Module):
 
     def predict_z0(self, latents, conditions, timesteps):
         """unifie.py:91-105 (training-side helper): per-sample timesteps via per-image bias rows."""
+        if self.__dict__.get("_stale"):
+            self.refresh()
         ops.set_dtype(self.dtype)
         lat = latents.shape[1]
         ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]

@@ -19,15 +19,6 @@ from .. import chain, ops
 from ..ops import UR_ACT_GEGLU, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_SILU
 
 DEV = "cuda"
-# SC-Tuner adapters as a parallel branch of the graph (side stream).  OFF by default since round 2.  With the branch on, replays
-# of a full-size forward differed (zt max |diff| ~0.09 at B=8): tools/det_trace.py traced it to the LDS-DMA GEMM kernels - a
-# write-after-read race on the K ring (the DMA of the next tile overwrote fragments whose reads were still outstanding across
-# the barrier) that only fired under LDS contention from a co-resident kernel.  Fixed in the kernels (lgkmcnt(0) in front of the
-# ring barriers, igemm_impl.h); graph replays are bit-identical with the branch on or off.  It stays off because it no longer
-# pays (314.9 vs 315.6 ms per batch) and eager (non-graph) runs with it on still show run-to-run differences at B=3.
-SIDE_STREAM = os.environ.get("UR_CSCE_STREAM", "0") == "1"
-side_stream = ops.side_stream
-
 FUSE_LN = __import__("os").environ.get("UR_FUSE_LN", "1") == "1"   # LayerNorm folded into the consuming GEMMs
 # Token-stationary fused chains (csrc/tchain.hip) for the 320-channel transformer blocks: 3 launches per Transformer2DModel
 # (HEAD chain, self-attention, TAIL chain) instead of 12.  UR_CHAIN=0 selects the per-layer path (A/B, and the shapes the

@@ -53,25 +53,10 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
-_SIDE = {}
-
-
-def side_stream() -> "torch.cuda.Stream":
-    """The per-device side stream on which independent branches of a forward run (parallel branches of the captured graph)."""
-    dev = torch.cuda.current_device()
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return _SIDE[dev]
-
-
 def workspace(dev, nbytes=192 << 20) -> torch.Tensor:
-    """Split-K partial planes: one FIXED-SIZE buffer for the side stream, one for everything else (kernels of the main branch -
-    whatever stream or capture it runs under - are ordered among themselves; the side branch runs concurrently with them).
-    Allocated once per device and never regrown (captured graphs keep its address); the library falls back to fewer splits
-    when a launch would not fit."""
-    cur = torch.cuda.current_stream()
-    on_side = any(cur == s for s in _SIDE.values())
-    key = (dev, "splitk", on_side)
+    """Split-K partial planes: ONE fixed-size buffer per device (every launch of a forward is ordered on one stream).  Allocated
+    once and never regrown (captured graphs keep its address); the library falls back to fewer splits when a launch would not fit."""
+    key = (dev, "splitk")
     if key not in _ws:
         _ws[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     return _ws[key]
