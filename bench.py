@@ -85,8 +85,8 @@ def cpu_baseline(model, denoise_steps):
     model.set_num_inference_steps(1)
     rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())
     parity = dict(sample="B=1 512x512, 1 DDIM step, same weights / image / noise as the oracle run",
-                  tolerance="bf16: <= 1.5x the emulated 16-bit-operand + stored-activation budget (oracle/emulate.py: z0 5.8e-3, zt 4.6e-3, "
-                            "image 4.7e-3); fp16: <= 1e-3 (north star)")
+                  tolerance="bf16: <= 1.25x the emulated 16-bit-operand + stored-activation budget (oracle/emulate.py BUDGET_FULLSIZE: z0 5.8e-3, "
+                            "zt 4.6e-3, image 4.7e-3); fp16: <= 1e-3 (north star)")
     for dt in ("bf16", "fp16"):
         model.set_dtype(dt)
         py, pz0, pzt = model(img, "ir", noise=noise, return_latents=True)
@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit storage / MFMA operand type (headline: bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the second timed loop in fp16 (headline dtype stays bf16)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the weight broadcast / output all-gather even "
                     "at world size 1 (exercises the N>1 code path - graph capture beside the RCCL watchdog - on a one-GPU box)")
     args = ap.parse_args()
@@ -160,6 +161,30 @@ def main():
         elapsed = float(t.item())
     finite = bool(torch.isfinite(out).all())
 
+    # ---- the same timed loop in fp16: the 16-bit type that meets the north-star 1e-3 parity (bf16 operands alone cost 3e-3) ----
+    fp16 = None
+    if args.dtype == "bf16" and not args.no_fp16:
+        model.set_dtype("fp16")
+        for _ in range(max(args.warmup, 1)):
+            step()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out16 = step()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e16 = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([e16], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e16 = float(t.item())
+        fp16 = {"images_per_s": world * B * args.steps / e16, "ms_per_step": e16 / args.steps * 1e3,
+                "output_finite": bool(torch.isfinite(out16).all())}
+        model.set_dtype("bf16")
+
     result = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -173,6 +198,8 @@ def main():
                        "parallelism": f"image-parallel dp{world}", "weights": "seeded random init (no checkpoints reachable)"},
             "images_per_s_per_gpu": B * args.steps / elapsed, "output_finite": finite,
         }
+        if fp16 is not None:
+            result["fp16"] = fp16
     # ---- live per-family kernel timing (eager pass, HIP events on the launch stream) --------------------------
     if rank == 0 and not args.no_profile:
         model.use_graph = False
@@ -186,7 +213,7 @@ def main():
         model.use_graph = True
         # every family against the roof that bounds it: contractions (conv / GEMM / attention) vs the dense 16-bit MFMA peak,
         # everything else (norm passes, stencils, layout kernels) vs HBM
-        MFMA_FAMS = ("conv3x3_igemm", "gemm1x1_igemm", "attention")
+        MFMA_FAMS = ("conv3x3_igemm", "gemm1x1_igemm", "attention", "chain_head", "chain_tail", "chain_mlp")
         fam = {}
         for k, v in rep.items():
             sec = v["ms"] / 1e3
@@ -202,7 +229,8 @@ def main():
         ach = (dom["flops"] / sec / 1e12) if mf else (dom["bytes"] / sec / 1e9)
         peak = MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBS
         names = {"conv3x3_igemm": "conv3x3 implicit GEMM (igemm_halo_kernel / igemm_halo_img_kernel + fallbacks)",
-                 "gemm1x1_igemm": "1x1 conv / Linear GEMMs (gemm_glds_kernel / igemm_kernel)", "attention": "flash attention (attn_fwd_kernel)"}
+                 "gemm1x1_igemm": "1x1 conv / Linear GEMMs (gemm_glds_kernel / igemm_kernel)", "attention": "flash attention (attn_fwd_kernel)",
+                 "chain_tail": "token-stationary transformer TAIL chain (tchain_tail_kernel)"}
         result["roofline"] = {"kernel": names.get(dom_name, dom_name) + ", all launches of one forward (the family with the most time)",
                               "family": dom_name, "bound": "mfma" if mf else "hbm", "achieved": round(ach, 1), "peak": peak,
                               "unit": "TFLOP/s" if mf else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
@@ -212,7 +240,7 @@ def main():
                               "share_of_forward": round(dom["ms"] / sum(v["ms"] for v in rep.values()), 3)}
         # HBM bytes of the most frequent launch of the conv family (conv3x3 320->320 @64x64, B=8), from separate rocprofv3 --pmc
         # passes (FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE), committed file; null for other families
-        for cand in ("r2_pmc_dominant.json", "r2_pmc_halo_conv.json"):
+        for cand in ("r3_pmc_halo_conv.json", "r2_pmc_dominant.json", "r2_pmc_halo_conv.json"):
             pmc = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
@@ -223,6 +251,8 @@ def main():
                     break
         result["families"] = fam
         result["profiled_forward_ms"] = round(sum(v["ms"] for v in rep.values()), 2)
+        # kernel nodes of the captured graph that come from this library (one per launch of the eager pass; torch adds a few copies)
+        result["library_launches_per_forward"] = int(sum(v["launches"] for v in rep.values()))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"], result["parity_vs_oracle"] = cpu_baseline(model, args.denoise_steps)
     if rank == 0:

@@ -7,7 +7,7 @@
   configs[4]  512x512, 50 steps, fp16: 50-step trajectory finite + deterministic at full size, 50-step PARITY on the tiny model
   + a 300x500 input (bicubic resize -> 512x853 -> reflect pad -> 512x896 -> un-pad -> resize back) and the config entry point.
 
-Tolerances = 1.5 x the values measured on MI355X (comments), per 16-bit type; the fp16 path meets the north-star 1e-3.
+Tolerances: bf16 = the emulated 16-bit error budget of the full-size architecture x 1.25 (oracle/emulate.py), fp16 = the north-star 1e-3.
 """
 import os
 import sys
@@ -20,9 +20,15 @@ from golden_util import rel_l2
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# measured rel-L2 (z0, zt, image) on MI355X x 1.5, full-size random-weight model
-# measured (r2): bf16 z0 5.4-5.7e-3, zt 3.1-4.0e-3, image 3.9-4.2e-3; fp16 z0 7.3-7.6e-4, zt 6.3-8.3e-4, image 5.2-5.7e-4
-TOL = {"bf16": (8.5e-3, 6.1e-3, 6.3e-3), "fp16": (1e-3, 1e-3, 1e-3)}      # fp16: the north-star bar itself
+# rel-L2 tolerances (z0, zt, image), full-size random-weight model.
+#   bf16: DERIVED from the CPU error budget, not from what the HIP path measured: oracle/emulate.py's "operands + stored
+#         activations" row of the full-size architecture x 1.25 (= 7.3e-3 / 5.8e-3 / 5.9e-3) - an implementation that rounds
+#         where a 16-bit pipeline must round lands there or below (measured r2-r3: 5.4-5.7e-3 / 3.1-4.1e-3 / 3.9-4.2e-3);
+#   fp16: the north-star bar itself, 1e-3 (the budget row x 1.25 would be 9.3e-4 / 7.0e-4 / 7.3e-4; measured 7.3e-4 / 6.3-8.3e-4 /
+#         5.2-5.7e-4: the HIP path rounds a few tensors the emulation keeps in fp32, e.g. LayerNorm-folded GEMM operands).
+from oracle.emulate import BUDGET_FULLSIZE, BUDGET_MARGIN
+
+TOL = {"bf16": tuple(BUDGET_MARGIN * v for v in BUDGET_FULLSIZE["bf16"]["storage"]), "fp16": (1e-3, 1e-3, 1e-3)}
 
 
 def _kw(steps):
