@@ -203,6 +203,12 @@ int ur_transformer_tail_fused(const void* o1, const void* h0, const void* xres, 
                               float* gn_part, long long T, int tokens_per_image, int C, int hidden, int heads, int tk, float ln_eps,
                               float attn_scale, int dtype, ur_stream_t stream);
 
+/* SC-Tuner adapter (CSCEAdapter, /root/reference/src/modules/diffuie/scedit.py:24-38) in one launch: s = x + proj(cond),
+ * y = tuner.2(GELU(tuner.0(s))) + s for a 320-channel UNet skip x [T][320] and the 256-channel Controller feature cond [T][256];
+ * gn_part (optional) as in ur_transformer_tail_fused (the edited skip feeds a GroupNorm on the up path).  stream_w: 14 tiles. */
+int ur_csce_fused(const void* x, const void* cond, const void* stream_w, size_t stream_bytes, void* y, float* gn_part, long long T,
+                  int tokens_per_image, int C, int Ccond, int dtype, ur_stream_t stream);
+
 /* ---- HBM-bound stencils / reductions / elementwise ---------------------------------------------*/
 /* depthwise 3x3 (pad 1) + bias, optional SimpleGate (out channels C/2): nafnet_arch.py:41-49,22-25 */
 int ur_dwconv3x3_nhwc(const void* x, const float* w9c, const float* bias, void* y, int N, int H, int W, int C,

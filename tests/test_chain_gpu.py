@@ -149,3 +149,61 @@ def test_transformer_tail_fused(ops, gn):
         assert torch.allclose(s[..., 1], (yf * yf).sum(1), rtol=1e-4, atol=1e-2)
     y2 = chain.transformer_tail_fused(o1.to(dt).cuda(), h0.to(dt).cuda(), x.to(dt).cuda(), st, n, 4 * c, heads, 77, 1e-5, 1 / 8.0, gn=gn)
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("hw", [128, 1024])
+def test_csce_fused(ops, hw):
+    """SC-Tuner adapter in one launch (scedit.py:24-38: s = x + proj(cond); out = tuner(s) + s) vs fp64 torch, and vs the three
+    per-layer GEMMs of the same module."""
+    from unirestore_amd import chain
+    from unirestore_amd.modules import adapters, nn as unn
+    dt = ops.act_dtype()
+    n, c, cc = 2, 320, 256
+    gen = torch.Generator().manual_seed(hw)
+    x = (torch.randn(n, hw, c, generator=gen) * 1.5).to(dt).float()
+    cond = (torch.randn(n, hw, cc, generator=gen)).to(dt).float()
+    wp, w0, w2 = (torch.randn(c, k, generator=gen) / math.sqrt(k) for k in (cc, c, c))
+    bp, b0, b2 = (torch.randn(c, generator=gen) * 0.1 for _ in range(3))
+    D = lambda t: t.double()
+    s = D(x) + F.linear(D(cond), D(wp), D(bp))
+    ref = (F.linear(F.gelu(F.linear(s, D(w0), D(b0))), D(w2), D(b2)) + s).float()
+    st = chain.pack_csce(wp, bp, w0, b0, w2, b2, "cuda")
+    assert st.numel() == 14 * chain.TILE
+    xg, cg = x.to(dt).cuda().view(n, hw // 32, 32, c), cond.to(dt).cuda().view(n, hw // 32, 32, cc)
+    y = chain.csce_fused(xg, cg, st)
+    yf = y.float().cpu().reshape(n, hw, c)
+    tol = 6e-3 if dt == torch.bfloat16 else 8e-4
+    assert rel_l2(yf - x, ref - x) < tol
+    part, parts = y._gn
+    assert parts == hw // 128 and tuple(part.shape) == (n, parts, c, 2)
+    sm = part.sum(1).cpu()
+    assert torch.allclose(sm[..., 0], yf.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sm[..., 1], (yf * yf).sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.equal(y, chain.csce_fused(xg, cg, st))
+    # the module takes the chain on its own and agrees with its per-layer path
+    m = adapters.CSCEAdapter(c, c, cc)
+    with torch.no_grad():
+        for p_, v in ((m.proj.weight, wp[:, :, None, None]), (m.proj.bias, bp), (m.tuner["0"].weight, w0[:, :, None, None]),
+                      (m.tuner["0"].bias, b0), (m.tuner["2"].weight, w2[:, :, None, None]), (m.tuner["2"].bias, b2)):
+            p_.copy_(v)
+    assert unn.CHAIN
+    ya = m.run(xg, cg)
+    assert torch.equal(ya, y)
+    unn.CHAIN = False
+    try:
+        yb = m.run(xg, cg)
+    finally:
+        unn.CHAIN = True
+    assert rel_l2(ya.float().cpu() - xg.float().cpu(), yb.float().cpu() - xg.float().cpu()) < 2 * tol
+
+
+def test_csce_fused_rejects_unsupported(ops):
+    from unirestore_amd import chain
+    dt = ops.act_dtype()
+    st = torch.zeros(14 * chain.TILE, dtype=torch.uint8, device="cuda")
+    x = torch.zeros(1, 96, 1, 320, dtype=dt, device="cuda")             # 96 tokens per image: not a multiple of 128
+    with pytest.raises(ValueError):
+        chain.csce_fused(x, torch.zeros(1, 96, 1, 256, dtype=dt, device="cuda"), st)
+    x = torch.zeros(1, 128, 1, 640, dtype=dt, device="cuda")
+    with pytest.raises(NotImplementedError):
+        chain.csce_fused(x, torch.zeros(1, 128, 1, 256, dtype=dt, device="cuda"), st)

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ur_ff_geglu_fused": (_I, [_P, _P, _SZ, _P, _LL, _I, _I, _I, _I, _F, _I, _P]),
     "ur_transformer_head_fused": (_I, [_P, _P, _P, _SZ, _P, _P, _P, _P, _LL, _I, _I, _F, _I, _P]),
     "ur_transformer_tail_fused": (_I, [_P, _P, _P, _P, _SZ, _P, _P, _LL, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
+    "ur_csce_fused": (_I, [_P, _P, _P, _SZ, _P, _P, _LL, _I, _I, _I, _I, _P]),
     "ur_dwconv3x3_nhwc": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ur_avgpool_hw": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     "ur_scale_channels": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

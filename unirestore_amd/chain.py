@@ -156,6 +156,30 @@ def pack_tail(wo1, bo1, wq2, g2, be2, wk2, wv2, ctx, wo2, bo2, w1, b1, w2, b2, g
     return torch.cat(tiles).contiguous()
 
 
+def pack_csce(w_proj, b_proj, w0, b0, w2, b2, dev, dt=None) -> torch.Tensor:
+    """CSCEAdapter (scedit.py:24-38) for a 320-channel skip and a 256-channel condition: proj (K = 256: 4 tiles), tuner.0, tuner.2."""
+    dt = dt or ops.act_dtype()
+    f = lambda t: t.detach().to(dev, torch.float32).reshape(t.shape[0], -1) if t.dim() > 1 else t.detach().to(dev, torch.float32)
+    w_proj, b_proj, w0, b0, w2, b2 = map(f, (w_proj, b_proj, w0, b0, w2, b2))
+    assert w_proj.shape == (CHAIN_C, 256) and w0.shape == (CHAIN_C, CHAIN_C) and w2.shape == (CHAIN_C, CHAIN_C)
+    tiles = gemm_tiles(w_proj, dt, aux_last=b_proj) + gemm_tiles(w0, dt, aux_last=b0) + gemm_tiles(w2, dt, aux_last=b2)
+    return torch.cat(tiles).contiguous()
+
+
+def csce_fused(x: torch.Tensor, cond: torch.Tensor, stream_w: torch.Tensor, gn=True) -> torch.Tensor:
+    """x [N,H,W,320], cond [N,H,W,256] 16-bit -> edited skip [N,H,W,320] (+ ._gn partial plane)"""
+    n, c = x.shape[0], x.shape[-1]
+    rows = x.numel() // c
+    hw = rows // n
+    y = torch.empty_like(x)
+    part = torch.empty((n, hw // CHAIN_TOK, c, 2), dtype=torch.float32, device=x.device) if gn else None
+    check(lib.ur_csce_fused(x.data_ptr(), cond.data_ptr(), stream_w.data_ptr(), stream_w.numel(), y.data_ptr(),
+                            None if part is None else part.data_ptr(), rows, hw, c, cond.shape[-1], ops._dt(x), ops._stream()))
+    if gn:
+        y._gn = (part, hw // CHAIN_TOK)
+    return y
+
+
 def chain_ok(x: torch.Tensor) -> bool:
     """The chain kernels cover C = 320 with whole 128-token tiles."""
     rows = x.numel() // x.shape[-1]

@@ -250,16 +250,16 @@ struct TChain {
   static __device__ __forceinline__ void unpack(const frag_t& f, float (&o)[8]) { unpack8t<F16>(__builtin_bit_cast(uint4, f), o); }
   static __device__ __forceinline__ frag_t pack(const float (&v)[8]) { return __builtin_bit_cast(frag_t, pack8t<F16>(v)); }
 
-  // out[2f+u] = 16-bit(acc + bias [+ residual res[2f+u]]) for the 10 fragments of a bias-only stage; `res` may alias `out`
-  template <bool RES>
+  // out[2f+u] = 16-bit(act(acc + bias) [+ residual res[2f+u]]) for the 10 fragments of a bias-only stage; `res` may alias `out`
+  template <bool RES, bool GELU = false>
   __device__ __forceinline__ void bias_res_pack(const f32x16 (&acc)[10], unsigned slot, const frag_t (&res)[20], frag_t (&out)[20]) const {
-    bias_res_pair<RES, 0>(acc, slot, res, out);
-    bias_res_pair<RES, 1>(acc, slot, res, out);
-    bias_res_pair<RES, 2>(acc, slot, res, out);
-    bias_res_pair<RES, 3>(acc, slot, res, out);
-    bias_res_pair<RES, 4>(acc, slot, res, out);
+    bias_res_pair<RES, GELU, 0>(acc, slot, res, out);
+    bias_res_pair<RES, GELU, 1>(acc, slot, res, out);
+    bias_res_pair<RES, GELU, 2>(acc, slot, res, out);
+    bias_res_pair<RES, GELU, 3>(acc, slot, res, out);
+    bias_res_pair<RES, GELU, 4>(acc, slot, res, out);
   }
-  template <bool RES, int FP>                               // two fragments at a time: 32 registers of bias values live
+  template <bool RES, bool GELU, int FP>                    // two fragments at a time: 32 registers of bias values live
   __device__ __forceinline__ void bias_res_pair(const f32x16 (&acc)[10], unsigned slot, const frag_t (&res)[20], frag_t (&out)[20]) const {
     float4 q[8];
     aux_vec4<0, 2 * FP>(slot, q);
@@ -271,6 +271,7 @@ struct TChain {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         v[e] = acc[f][8 * u + e] + f4e(q[2 * i + (e >> 2)], e & 3);
+        if constexpr (GELU) v[e] = gelu_f(v[e]);
         if constexpr (RES) v[e] += r[e];
       }
       out[2 * f + u] = pack(v);
@@ -551,6 +552,83 @@ __global__ __launch_bounds__(256, 1) void tchain_head_kernel(const HeadP p) {
   }
 }
 
+// GroupNorm statistics of a workgroup's [128 tokens][320] tile of 16-bit values (fragments y of every wave): tile -> LDS
+// [128][656 B] (row pad: conflict-free column reads), 160 threads add one channel pair each over the 128 rows in a fixed order ->
+// this tile's slot of the partial plane [N][tokens_per_image / 128][320][2].  The ring must be drained (its memory is reused).
+template <bool F16>
+__device__ __forceinline__ void gn_partials_of_tile(const TChain<F16>& tc, unsigned char* smem, const typename Frag<F16>::type (&y)[20],
+                                                    float* gn_part, long long tok0, int tok_per_img) {
+  typedef typename Frag<F16>::type frag_t;
+  constexpr int C = 320, ROW = 2 * C + 16;
+  unsigned char* yt = smem + (tc.wid * 32 + (tc.lane & 31)) * ROW + 16 * tc.h;
+#pragma unroll
+  for (int s = 0; s < 20; ++s) *reinterpret_cast<frag_t*>(yt + 32 * s) = y[s];
+  __syncthreads();
+  if (threadIdx.x < C / 2) {
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    for (int r = 0; r < TC_TOK; ++r) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * ROW + threadIdx.x * 4);
+      const float a = Act<F16>::lo(w), b = Act<F16>::hi(w);
+      s0 += a; q0 = fmaf(a, a, q0); s1 += b; q1 = fmaf(b, b, q1);
+    }
+    const int img = (int)(tok0 / tok_per_img), parts = tok_per_img / TC_TOK;
+    const int part = (int)((tok0 - (long long)img * tok_per_img) / TC_TOK);
+    float* st = gn_part + (((long long)img * parts + part) * C + 2 * threadIdx.x) * 2;
+    *reinterpret_cast<float4*>(st) = make_float4(s0, q0, s1, q1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kind CSCE (SC-Tuner, /root/reference/src/modules/diffuie/scedit.py:24-38): s = x + proj(cond); out = tuner.2(GELU(tuner.0(s))) + s,
+// x = a UNet skip [T][320], cond = the Controller feature of the same resolution [T][256]; + GroupNorm partial sums of out.
+// Stream: proj (4 tiles of 320 rows x 64 k; aux of the last = bias) | tuner.0 (5, bias) | tuner.2 (5, bias).
+struct CsceP {
+  const unsigned char* stream;
+  const uint16_t* x;             // [T][320]
+  const uint16_t* cond;          // [T][256]
+  uint16_t* y;                   // [T][320]
+  float* gn_part;                // [N][tok_per_img / 128][320][2] or null
+  int T, tok_per_img, ntiles;
+};
+
+template <bool F16>
+__global__ __launch_bounds__(256, 1) void tchain_csce_kernel(const CsceP p) {
+  typedef typename Frag<F16>::type frag_t;
+  constexpr int C = 320, CC = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  TChain<F16> tc;
+  tc.init(smem, p.stream, p.ntiles);
+  const long long tok0 = (long long)blockIdx.x * TC_TOK;
+  const long long tok = tok0 + tc.wid * 32 + (tc.lane & 31);
+  frag_t sb[20], hb[20];
+  {                                                     // cond fragments: 16 k-steps, parked in hb until proj has consumed them
+    const uint16_t* cp = p.cond + tok * CC + 8 * tc.h;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) hb[s] = *reinterpret_cast<const frag_t*>(cp + 16 * s);
+  }
+  f32x16 acc[10];
+  zero_acc(acc);
+  // s = x + proj(cond) + b: 4 k tiles; the skip x is fetched behind the third (80 registers less during the others)
+  unsigned slot = tc.acquire();
+  tc.template gemm_tile<true>(acc, hb[0], hb[1], hb[2], hb[3], slot);
+#pragma unroll
+  for (int kt = 1; kt < 4; ++kt) {
+    slot = tc.acquire();
+    tc.template gemm_tile<false>(acc, hb[4 * kt], hb[4 * kt + 1], hb[4 * kt + 2], hb[4 * kt + 3], slot);
+    if (kt == 2) load_frags<F16>(p.x, token_again(), C, tc.h, sb);
+  }
+  tc.template bias_res_pack<true>(acc, slot, sb, sb);
+  // h = GELU(tuner.0(s) + b)
+  slot = tc.gemm_stage(acc, sb);
+  tc.template bias_res_pack<false, true>(acc, slot, hb, hb);
+  // out = tuner.2(h) + b + s
+  slot = tc.gemm_stage(acc, hb);
+  tc.template bias_res_pack<true>(acc, slot, sb, sb);
+  store_frags<F16>(p.y, token_again(), C, tc.h, sb);
+  tc.drain();
+  if (p.gn_part) gn_partials_of_tile<F16>(tc, smem, sb, p.gn_part, tok0, p.tok_per_img);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // kind TAIL: everything of a BasicTransformerBlock behind the self-attention + Transformer2DModel.proj_out:
 //   h1 = h0 + to_out1(o1) + b;  q2 = to_q2(LayerNorm2(h1));  o2 = softmax(q2 Kc^T / 8) Vc per head (constant context, <= 80 keys);
@@ -669,27 +747,7 @@ __global__ __launch_bounds__(256, 1) void tchain_tail_kernel(const TailP p) {
   tc.template bias_res_pack<true>(acc, slot, xq, xq);
   store_frags<F16>(p.y, tok2, C, tc.h, xq);
   tc.drain();                                        // no LDS-DMA may outlive the workgroup; the ring memory is free now
-  if (p.gn_part) {
-    // GroupNorm statistics of the 16-bit values just written: tile -> LDS [128 tokens][656 B] (row pad: conflict-free column reads),
-    // 160 threads add one channel pair each over the 128 rows in a fixed order -> this tile's slot of the partial plane
-    constexpr int ROW = 2 * C + 16;
-    unsigned char* yt = smem + (tc.wid * 32 + (tc.lane & 31)) * ROW + 16 * tc.h;
-#pragma unroll
-    for (int s = 0; s < 20; ++s) *reinterpret_cast<frag_t*>(yt + 32 * s) = xq[s];
-    __syncthreads();
-    if (threadIdx.x < C / 2) {
-      float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-      for (int r = 0; r < TC_TOK; ++r) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + r * ROW + threadIdx.x * 4);
-        const float a = Act<F16>::lo(w), b = Act<F16>::hi(w);
-        s0 += a; q0 = fmaf(a, a, q0); s1 += b; q1 = fmaf(b, b, q1);
-      }
-      const int img = (int)(tok0 / p.tok_per_img), parts = p.tok_per_img / TC_TOK;
-      const int part = (int)((tok0 - (long long)img * p.tok_per_img) / TC_TOK);
-      float* st = p.gn_part + (((long long)img * parts + part) * C + 2 * threadIdx.x) * 2;
-      *reinterpret_cast<float4*>(st) = make_float4(s0, q0, s1, q1);
-    }
-  }
+  if (p.gn_part) gn_partials_of_tile<F16>(tc, smem, xq, p.gn_part, tok0, p.tok_per_img);
 }
 
 template <bool F16>
@@ -701,6 +759,16 @@ int launch_head(const HeadP& p, hipStream_t s) {
   }
   hipLaunchKernelGGL((tchain_head_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);
   return ur::check_launch("ur_transformer_head_fused");
+}
+template <bool F16>
+int launch_csce(const CsceP& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&tchain_csce_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((tchain_csce_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);
+  return ur::check_launch("ur_csce_fused");
 }
 template <bool F16>
 int launch_tail(const TailP& p, hipStream_t s) {
@@ -773,5 +841,22 @@ extern "C" int ur_transformer_tail_fused(const void* o1, const void* h0, const v
   const double flops = 2.0 * (double)T * C * (4.0 * C + 3.0 * hidden) + 4.0 * (double)T * tk * C;
   ur::ProfScope prof("chain_tail", flops, 2.0 * (double)T * C * 4 + (double)p.ntiles * TC_TILE, s);
   UR_DT_SWITCH(dtype, return (launch_tail<F16>(p, s)));
+  return UR_OK;
+}
+
+extern "C" int ur_csce_fused(const void* x, const void* cond, const void* stream_w, size_t stream_bytes, void* y, float* gn_part, long long T,
+                             int tokens_per_image, int C, int Ccond, int dtype, ur_stream_t stream) {
+  UR_REQUIRE(x && cond && stream_w && y, "null pointer");
+  UR_REQUIRE_DT(dtype);
+  if (C != 320 || Ccond != 256) return ur::fail(UR_E_UNSUPPORTED, "ur_csce_fused: C must be 320 and the condition 256 channels wide");
+  UR_REQUIRE(T > 0 && tokens_per_image > 0 && tokens_per_image % TC_TOK == 0 && T % tokens_per_image == 0 && T * (long long)C < (1ll << 31),
+             "tokens per image must be a multiple of 128 and divide T");
+  CsceP p = {};
+  p.stream = (const unsigned char*)stream_w; p.x = (const uint16_t*)x; p.cond = (const uint16_t*)cond; p.y = (uint16_t*)y; p.gn_part = gn_part;
+  p.T = (int)T; p.tok_per_img = tokens_per_image; p.ntiles = 14;
+  UR_REQUIRE(stream_bytes >= (size_t)p.ntiles * TC_TILE, "weight stream too short");
+  hipStream_t s = (hipStream_t)stream;
+  ur::ProfScope prof("chain_csce", 2.0 * (double)T * C * (Ccond + 2.0 * C), 2.0 * (double)T * (2.0 * C + Ccond) + (double)p.ntiles * TC_TILE, s);
+  UR_DT_SWITCH(dtype, return (launch_csce<F16>(p, s)));
   return UR_OK;
 }

@@ -7,8 +7,9 @@ tensors like the reference operators, `run` is the NHWC bf16 fast path the model
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import chain, ops
 from ..ops import UR_ACT_GATE, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_RELU, UR_ACT_TANH
+from . import nn as _nn
 from .nn import DEV, Conv2d, LayerNorm, Linear, GroupNorm
 
 
@@ -33,6 +34,14 @@ class CSCEAdapter(nn.Module):
         self.tuner = _named(_0=Conv2d(c_in, c_emb, 1), _2=Conv2d(c_emb, c_in, 1))
 
     def run(self, x, condition):
+        n, hh, ww, c = x.shape
+        if (_nn.CHAIN and c == chain.CHAIN_C and condition.shape[-1] == 256 and self.tuner["0"].out_channels == c and
+                (hh * ww) % chain.CHAIN_TOK == 0 and x.is_contiguous() and condition.is_contiguous()):
+            key = ("cache", "chain", ops.act_dtype())          # one launch: the token-stationary chain (csrc/tchain.hip, kind CSCE)
+            if key not in self.__dict__:
+                self.__dict__[key] = chain.pack_csce(self.proj.weight, self.proj.bias, self.tuner["0"].weight, self.tuner["0"].bias,
+                                                     self.tuner["2"].weight, self.tuner["2"].bias, DEV)
+            return chain.csce_fused(x, condition, self.__dict__[key])
         s = ops.conv(condition, self.proj.packed(), residual=x)               # s = x + proj(cond)
         h = ops.conv(s, self.tuner["0"].packed(), act=UR_ACT_GELU)
         return ops.conv(h, self.tuner["2"].packed(), residual=s, gn=True)     # tuner(s) + s (feeds a GroupNorm in the up path)
