@@ -52,7 +52,7 @@ def build(force=False, verbose=True):
         cmd = [cc, *FLAGS, *EXTRA, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "unirestore_hip.h")]
         if src.startswith("igemm"):
-            deps.append(os.path.join(CSRC, "igemm_impl.h"))
+            deps += [os.path.join(CSRC, "igemm_impl.h"), os.path.join(CSRC, "igemm_asm.inc")]
         if src.startswith("attention"):
             deps.append(os.path.join(CSRC, "attention_params.h"))
         if src.startswith("tchain"):

@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
   const int frow = lane & 31, fhalf = lane >> 5;
-  const int ntile = p.nk;
+  const int ntile = (p.dbg & 8) ? 0 : p.nk;               // (dbg bits: timing-only ablations, UR_IGEMM_DBG)
   int issued = 0;
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
@@ -1101,6 +1101,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
     if (issued < ntile) { issue_tile(is); ++issued; is = (is + 1 == NST) ? 0 : is + 1; }
     const unsigned char* xs = smem + cs * STAGE;
     const unsigned char* wsm = xs + BM * 128;
+    if (!(p.dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int slot = ks * 2 + fhalf;
@@ -1126,6 +1127,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+  if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.y)[0] = 1.f; return; }
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, DIRECT, PAIRC>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
 }
 
@@ -1204,6 +1206,51 @@ __device__ __forceinline__ void gn_piece_inplace(unsigned char* piece, const GnA
   *reinterpret_cast<uint4*>(piece) = pack8t<F16>(f);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One 64-deep K tile of a wave's FM x FN fragment tile out of LDS, hand-scheduled (igemm_asm.inc, tools/gen_igemm_asm.py):
+// fragment reads run a register pool ahead of the MFMAs, every MFMA waits with a counted lgkmcnt for its own operands.
+// ab[b] = LDS byte address of activation fragment b at k-step 0 (row * 128 + ((lane half ^ swizzle) << 4)), aw = the same for the
+// wave's first weight fragment (fragment a: + a * 4096); rows are 128-byte, 128-aligned, slots XOR-swizzled with (row >> 1) & 7.
+#if UR_IGASM_ABL == 4
+#include "igemm_asm_abl4.inc"
+#elif UR_IGASM_ABL == 5
+#include "igemm_asm_abl5.inc"
+#else
+#include "igemm_asm.inc"
+#endif
+#ifndef UR_HALO_ABL
+#define UR_HALO_ABL 0      // timing-only ablations of igemm_halo_kernel (A/B builds): 1 = no DMA waits, 2 = no MFMA body
+#endif
+typedef uint32_t ig_u32x4 __attribute__((ext_vector_type(4)));
+#define IG_MN(ASM, ...)                                                                      \
+  do {                                                                                       \
+    if constexpr (F16) asm volatile(ASM("v_mfma_f32_32x32x16_f16") __VA_ARGS__);             \
+    else asm volatile(ASM("v_mfma_f32_32x32x16_bf16") __VA_ARGS__);                          \
+  } while (0)
+template <int FM, int FN, bool F16>
+__device__ __forceinline__ void ktile_mma(f32x16 (&acc)[FN][FM], const unsigned (&ab)[FM], unsigned aw) {
+  ig_u32x4 t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
+  unsigned x0, x1, xw;
+  if constexpr (FM == 1 && FN == 5) {
+    IG_MN(IG_ASM_KT_1x5, : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[4][0]),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(t8), "=&v"(t9), "=&v"(x0), "=&v"(xw)
+          : "v"(ab[0]), "v"(aw) : "memory");
+  } else if constexpr (FM == 2 && FN == 2) {
+    IG_MN(IG_ASM_KT_2x2, : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(x0), "=&v"(x1), "=&v"(xw)
+          : "v"(ab[0]), "v"(ab[1]), "v"(aw) : "memory");
+  } else {
+    static_assert(FM == 0, "no hand-scheduled K tile for this fragment shape");
+  }
+}
+template <int FM, int FN> constexpr bool ktile_asm_ok() {
+#ifdef UR_IGEMM_NOASM
+  return false;
+#else
+  return (FM == 1 && FN == 5) || (FM == 2 && FN == 2);
+#endif
+}
+
 // =====================================================================================================================
 // Halo-tile 3x3 convolution (stride 1, pad 1, optional nearest-2x upsampled input).
 // The L2 -> CU ingest path, not the MFMA pipe, bounds the implicit GEMM (about 13 B/clk/CU: ~8 KB in flight against
@@ -1276,7 +1323,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     woff[i] = row < p.Cout ? row * p.ldw : -1;
   }
   // blockIdx.y splits the channel-chunk range (few-tile layers: tiles * splits <= one round of CUs)
+#if UR_HALO_ABL == 3                                          // timing-only: prologue + epilogue, no K loop
+  const int cps = p.nk_per_split / 9, c_begin = sz * cps, nchunk = p.N < 0 ? 1 : 0;
+#else
   const int cps = p.nk_per_split / 9, c_begin = sz * cps, nchunk = min(p.nk / 9, c_begin + cps) - c_begin;
+#endif
   const int nk = nchunk * 9, kt0 = c_begin * 9;
 
   auto issue_w = [&](int kt, int ring) {
@@ -1318,6 +1369,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
   const int frow = lane & 31, fhalf = lane >> 5;
+  // LDS byte addresses for the hand-scheduled tap body: halo buffer 0, and this wave's first weight fragment at k-step 0 in ring slot 0
+  const unsigned hb_lds = (unsigned)(uintptr_t)(lptr_t)hbuf;
+  const unsigned aw_lds = (unsigned)(uintptr_t)(lptr_t)wring + (wn * WTN + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  static_assert(((WTN >> 1) & 7) == 0, "the wave's weight rows must keep the swizzle phase of fragment row 0");
 
   // ---- prologue: whole halo of chunk 0, weight tiles 0 and 1 ------------------------------------------------------------
   if (gnp) issue_ab(0);
@@ -1355,7 +1410,18 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
       // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it in LDS next to this tap's MFMAs
       // (splitting the two waves of a SIMD to opposite sides of the MFMA block measured no gain and cost registers)
       if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
-      {
+      if constexpr (ktile_asm_ok<FM, FN>()) {
+        const int dy = tap / 3, dx = tap % 3;
+        unsigned ab[FM];
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+          const int hrow = (wm * FM + b + dy) * PW + dx + frow;
+          ab[b] = hb_lds + (c & 1) * HBYTES + hrow * 128 + ((fhalf ^ ((hrow >> 1) & 7)) << 4);
+        }
+#if UR_HALO_ABL != 2                                        // (2: timing-only, no MFMA body)
+        ktile_mma<FM, FN, F16>(acc, ab, aw_lds + (tap % 3) * WBYTES);
+#endif
+      } else {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
         typedef typename Frag<F16>::type frag_t;
@@ -1384,13 +1450,20 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
         }
       }
       // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
+#if UR_HALO_ABL == 1                                        // timing-only: never wait for the DMA
+      if (false) {
+#else
       if (ab_now) {                                       // tap 0 with the next chunk's affine table in flight as well
+#endif
         if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      } else if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
+      }
+#if UR_HALO_ABL != 1
+      else if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
       else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
       else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       // lgkmcnt(0): (1) this wave's fragment reads of the ring slot / halo buffer that the NEXT tap's DMA overwrites are retired
       // before anyone passes the barrier (hipcc leaves the last reads outstanding across it otherwise - see igemm_glds_kernel);
       // (2) the in-place GroupNorm writes are published by the barrier
@@ -1398,7 +1471,12 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
       __builtin_amdgcn_s_barrier();
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // last MFMA of the asm tap body -> VALU reads of the accumulators
+#if UR_HALO_ABL == 4                                          // timing-only: no epilogue (one store keeps the loop alive)
+  if (acc[0][0][0] == 123.456f) reinterpret_cast<uint16_t*>(p.y)[0] = 1;
+#else
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+#endif
 }
 
 template <int TH, int BN, int WM, int WN>
@@ -1554,6 +1632,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
     hrow0[b] = im * HP + hin0[b];
     hy0[b] = y;
   }
+  const unsigned hb_lds = (unsigned)(uintptr_t)(lptr_t)hbuf;
+  const unsigned aw_lds = (unsigned)(uintptr_t)(lptr_t)wring + (wn * WTN + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  static_assert(((WTN >> 1) & 7) == 0, "the wave's weight rows must keep the swizzle phase of fragment row 0");
 
   if (gnp) issue_ab(0);
 #pragma unroll
@@ -1587,7 +1668,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
       // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it in LDS next to this tap's MFMAs
       // (splitting the two waves of a SIMD to opposite sides of the MFMA block measured no gain and cost registers)
       if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
-      {
+      if constexpr (ktile_asm_ok<FM, FN>()) {
+        const int dy = tap / 3, dx = tap % 3;
+        unsigned ab[FM];
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+          const int hsw = (((hin0[b] + dy * PW + dx) >> 1) - (hy0[b] + dy)) & 7;
+          ab[b] = hb_lds + (c & 1) * HBYTES + (hrow0[b] + dy * PW + dx) * 128 + ((fhalf ^ hsw) << 4);
+        }
+        ktile_mma<FM, FN, F16>(acc, ab, aw_lds + (tap % 3) * WBYTES);
+      } else {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
         int hro[FM], hsw[FM];
@@ -1628,6 +1718,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
       __builtin_amdgcn_s_barrier();
     }
   }
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // last MFMA of the asm tap body -> VALU reads of the accumulators
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 }
 
