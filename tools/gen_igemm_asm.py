@@ -90,6 +90,126 @@ def ktile(name, fm, fn, pool, pad=False):
     return fmt(name, hdr, lines)
 
 
+def ktile_pipe(name, fm, fn, pa_n, pb_n, split):
+    """Tap-crossing software pipeline (halo convs): the fragment reads of a K tile's first k-step are issued by the PREVIOUS tile's
+    block, so the matrix pipe does not drain at the per-tile barrier.  One K tile = two asm blocks with the workgroup's
+    "next weight tile has landed" wait + barrier between them (the caller's C++):
+        NAME_PRE   reads of k-step 0 of the first tile (addresses = the "next" operands)
+        NAME_H1    MFMAs 0 .. split-1
+        NAME_H2    MFMAs split .. end + reads of k-step 0 of the next tile ("next" addresses; its weights were published by the
+                   barrier in front of this block)
+        NAME_H2L   the same without the prefetch (last tile)
+    Fragment registers are two rings that persist ACROSS blocks ("+v" operands): weight read j of a tile lives in A[j % pa_n],
+    activation read j in B[j % pb_n] (reads per tile are multiples of the ring sizes, so the mapping is the same for every tile).
+    lgkmcnt is counted over the whole stream: at block entry exactly fm + fn prefetch reads are outstanding (LDS ops the compiler
+    issued in between are younger and only make the counted waits stricter).
+    Operands (identical lists for all four): accumulators, pa_n + pb_n ring registers ("+v"), fm + 1 address temporaries ("=&v"),
+    then inputs: fm activation addresses + weight address of THIS tile, the same of the NEXT tile."""
+    n_acc = fm * fn
+    assert (4 * fn) % pa_n == 0 and (4 * fm) % pb_n == 0
+    o_acc, o_pa = 0, n_acc
+    o_pb = o_pa + pa_n
+    o_xb = o_pb + pb_n
+    o_xw = o_xb + fm
+    o_ab = o_xw + 1
+    o_aw = o_ab + fm
+    o_abn = o_aw + 1
+    o_awn = o_abn + fm
+    assert o_awn + 1 <= 30, name
+    mfmas = [(ks, a, b) for ks in range(4) for a in range(fn) for b in range(fm)]
+    reads, last = [], {}
+    for i, (ks, a, b) in enumerate(mfmas):
+        for key in (("B", ks, b), ("A", ks, a)):
+            if key not in last:
+                reads.append(key)
+            last[key] = i
+    npre = fm + fn
+    assert all(k[1] == 0 for k in reads[:npre])
+
+    def reg(key):
+        kind, ks, idx = key
+        return (o_pb + (ks * fm + idx) % pb_n) if kind == "B" else (o_pa + (ks * fn + idx) % pa_n)
+
+    def read_line(key, nxt, xor_done, lines):
+        kind, ks, idx = key
+        base_b, base_w = (o_abn, o_awn) if nxt else (o_ab, o_aw)
+        if ks > 0:
+            tag = (kind, ks, idx if kind == "B" else 0)
+            if tag not in xor_done:
+                xor_done.add(tag)
+                dst, src = (o_xb + idx, base_b + idx) if kind == "B" else (o_xw, base_w)
+                lines.append(f"v_xor_b32 %{dst}, {hex(ks << 5)}, %{src}")
+        if kind == "B":
+            addr, off = ((base_b + idx) if ks == 0 else (o_xb + idx)), 0
+        else:
+            addr, off = (base_w if ks == 0 else o_xw), idx * 4096
+        lines.append(f"ds_read_b128 %{reg(key)}, %{addr}" + (f" offset:{off}" if off else ""))
+
+    out = ""
+    # PRE
+    lines = []
+    for key in reads[:npre]:
+        read_line(key, True, set(), lines)
+    out += fmt(name + "_PRE", f"reads of k-step 0 of the first tile ({npre}), next-tile address operands", lines)
+
+    for variant in ("", "L"):
+        # simulate one steady-state tile; seq numbers: prefetched reads 0..npre-1
+        issued = list(reads[:npre])                    # this tile's reads issued so far (stream order)
+        total = npre                                   # reads issued in the whole stream up to now (for lgkmcnt)
+        seq = {k: i for i, k in enumerate(issued)}
+        occupant_dead_at = {}                          # ring register -> MFMA index after which it is free (-1 = free)
+        for k in issued:
+            occupant_dead_at[reg(k)] = last[k]
+        nxt_issued = 0
+        halves = {1: [], 2: []}
+        xor_done = {1: set(), 2: set()}
+
+        def try_issue(i_done, half, limit):
+            """issue up to `limit` reads of the stream whose ring register is free after MFMA i_done"""
+            nonlocal total, nxt_issued
+            n = 0
+            while n < limit:
+                if len(issued) < len(reads):
+                    key, nxt = reads[len(issued)], False
+                elif half == 2 and variant == "" and nxt_issued < npre:
+                    key, nxt = reads[nxt_issued], True
+                else:
+                    return
+                r = reg(key)
+                if occupant_dead_at.get(r, -1) > i_done:
+                    return
+                read_line(key, nxt, xor_done[half] if not nxt else set(), halves[half])
+                if nxt:
+                    nxt_issued += 1
+                    occupant_dead_at[r] = 10 ** 9      # lives into the next tile
+                else:
+                    issued.append(key)
+                    seq[key] = total
+                    occupant_dead_at[r] = last[key]
+                total += 1
+                n += 1
+
+        for i, (ks, a, b) in enumerate(mfmas):
+            half = 1 if i < split else 2
+            ka, kb = ("A", ks, a), ("B", ks, b)
+            while ka not in seq or kb not in seq:
+                before = total
+                try_issue(i - 1, half, 1)
+                assert total > before, (name, "ring too small", i)
+            need = max(seq[ka], seq[kb])
+            halves[half].append(f"s_waitcnt lgkmcnt({total - 1 - need})")
+            halves[half].append(f"@MN@ %{o_acc + a * fm + b}, %{reg(ka)}, %{reg(kb)}, %{o_acc + a * fm + b}")
+            try_issue(i, half, 2)
+        try_issue(len(mfmas) - 1, 2, 99)               # whatever prefetch is left
+        if variant == "":
+            assert nxt_issued == npre and len(issued) == len(reads), name
+            out += fmt(name + "_H1", f"MFMAs 0..{split - 1} of a tile ({npre} prefetched reads outstanding at entry)", halves[1])
+            out += fmt(name + "_H2", f"MFMAs {split}..{len(mfmas) - 1} + the {npre} k-step-0 reads of the next tile", halves[2])
+        else:
+            out += fmt(name + "_H2L", f"MFMAs {split}..{len(mfmas) - 1} of the last tile (nothing outstanding at exit)", halves[2] + ["s_nop 15", "s_nop 7"])
+    return out
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     for abl in (4, 5, 0):             # timing-only variants (4 = no fragment reads, 5 = no MFMAs) for A/B builds, then the real file
@@ -108,6 +228,8 @@ def write(out):
     txt += ktile("IG_ASM_KT_4x2", 4, 2, 8)
     txt += ktile("IG_ASM_KT_1x4", 1, 4, 8)
     txt += ktile("IG_ASM_KT_4x1", 4, 1, 8)
+    txt += ktile_pipe("IG_ASM_KP_1x5", 1, 5, 10, 4, 10)
+    txt += ktile_pipe("IG_ASM_KP_2x2", 2, 2, 8, 4, 8)
     open(out, "w").write(txt)
     print("wrote", os.path.normpath(out))
 

@@ -1,4 +1,4 @@
 #!/bin/bash
-# scratch GPU script
-cd /root/repo/tools/probe
-for f in p2_*; do timeout 60 ./$f 2>&1 | grep -v amdgpu.ids; done | tee /root/repo/gpurun_out/probe2.txt
+cd /root/repo
+export TMPDIR=/tmp
+for t in ts ts_stag; do echo "== $t"; UR_LIB=$PWD/unirestore_amd/ab/libur_$t.so timeout 300 python tools/halo_ts.py 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/halo_ts.txt

@@ -1243,12 +1243,81 @@ __device__ __forceinline__ void ktile_mma(f32x16 (&acc)[FN][FM], const unsigned 
     static_assert(FM == 0, "no hand-scheduled K tile for this fragment shape");
   }
 }
+// LDS-DMA of one 1-KiB piece (64 lanes x 16 bytes -> LDS bytes [m0v, m0v + 1024)) through a raw buffer descriptor: lane address =
+// base + voff + soff, and a lane whose voff is past num_records reads ZERO - the convolution's zero padding, ragged Cout rows and
+// the K tail cost no select, no zero page and no 64-bit address arithmetic (the global_load_lds form needed ~10 VALU + a
+// v_readfirstlane for M0 per piece: ~45 instructions per tap and wave in front of the MFMAs, 27 % of the dominant conv launch).
+// Invisible to hipcc's s_waitcnt bookkeeping: the callers count vmcnt themselves (they did before, too).
+constexpr unsigned IG_OOB = 0xffffff00u;       // voffset of a lane that must read zeros (>= every num_records used here)
+__device__ __forceinline__ ig_u32x4 ig_make_rsrc(const void* base, unsigned long long bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  ig_u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);         // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((unsigned)(bytes < IG_OOB ? bytes : IG_OOB));
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void ig_lds_dma16(unsigned m0v, unsigned voff, const ig_u32x4& rs, unsigned soff) {
+  // (readfirstlane: free when hipcc already knows the value is wave-uniform, and keeps an "s" operand out of a VGPR when it does not)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(rs),
+               "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+
 template <int FM, int FN> constexpr bool ktile_asm_ok() {
 #ifdef UR_IGEMM_NOASM
   return false;
 #else
   return (FM == 1 && FN == 5) || (FM == 2 && FN == 2);
 #endif
+}
+
+// Tap-crossing software pipeline of the halo convs (igemm_asm.inc, ktile_pipe in tools/gen_igemm_asm.py): the K tile's MFMAs are two
+// asm blocks (PHASE 1 = first half, 2 = second half + the first fragment reads of the NEXT tile, 3 = second half of the last tile)
+// with the workgroup's "next weight tile landed" wait + barrier between them; PHASE 0 issues the first tile's prefetch.  The
+// fragment rings ra / rb live across the blocks.  Without it the matrix pipe drains at every per-tile barrier: the first MFMA
+// behind the barrier waits a full LDS round trip (~150-250 of ~1300 cycles per tile, tools/probe + UR_IGASM_ABL timings).
+template <int FM, int FN> struct KPipeRings { ig_u32x4 ra[FN == 5 ? 10 : 8], rb[4]; };
+template <int FM, int FN, bool F16, int PHASE>
+__device__ __forceinline__ void kpipe(f32x16 (&acc)[FN][FM], KPipeRings<FM, FN>& r, const unsigned (&ab)[FM], unsigned aw, const unsigned (&abn)[FM],
+                                      unsigned awn) {
+  unsigned x0, x1, xw;
+#define KP_OPS_1x5 : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[4][0]),                                        \
+      "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]), "+v"(r.ra[4]), "+v"(r.ra[5]), "+v"(r.ra[6]), "+v"(r.ra[7]), "+v"(r.ra[8]), "+v"(r.ra[9]), \
+      "+v"(r.rb[0]), "+v"(r.rb[1]), "+v"(r.rb[2]), "+v"(r.rb[3]), "=&v"(x0), "=&v"(xw) : "v"(ab[0]), "v"(aw), "v"(abn[0]), "v"(awn) : "memory"
+#define KP_OPS_2x2 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),                                                          \
+      "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]), "+v"(r.ra[4]), "+v"(r.ra[5]), "+v"(r.ra[6]), "+v"(r.ra[7]),                       \
+      "+v"(r.rb[0]), "+v"(r.rb[1]), "+v"(r.rb[2]), "+v"(r.rb[3]), "=&v"(x0), "=&v"(x1), "=&v"(xw)                                                   \
+      : "v"(ab[0]), "v"(ab[1]), "v"(aw), "v"(abn[0]), "v"(abn[1]), "v"(awn) : "memory"
+  if constexpr (FM == 1 && FN == 5) {
+    if constexpr (PHASE == 0) IG_MN(IG_ASM_KP_1x5_PRE, KP_OPS_1x5);
+    else if constexpr (PHASE == 1) IG_MN(IG_ASM_KP_1x5_H1, KP_OPS_1x5);
+    else if constexpr (PHASE == 2) IG_MN(IG_ASM_KP_1x5_H2, KP_OPS_1x5);
+    else IG_MN(IG_ASM_KP_1x5_H2L, KP_OPS_1x5);
+  } else if constexpr (FM == 2 && FN == 2) {
+    if constexpr (PHASE == 0) IG_MN(IG_ASM_KP_2x2_PRE, KP_OPS_2x2);
+    else if constexpr (PHASE == 1) IG_MN(IG_ASM_KP_2x2_H1, KP_OPS_2x2);
+    else if constexpr (PHASE == 2) IG_MN(IG_ASM_KP_2x2_H2, KP_OPS_2x2);
+    else IG_MN(IG_ASM_KP_2x2_H2L, KP_OPS_2x2);
+  } else {
+    static_assert(FM == 0, "no pipelined K tile for this fragment shape");
+  }
+#undef KP_OPS_1x5
+#undef KP_OPS_2x2
+}
+template <int FM, int FN> __device__ __forceinline__ void kpipe_drain(KPipeRings<FM, FN>& r) {
+  if constexpr (FN == 5)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]), "+v"(r.ra[4]), "+v"(r.ra[5]), "+v"(r.ra[6]), "+v"(r.ra[7]),
+                 "+v"(r.ra[8]), "+v"(r.ra[9]), "+v"(r.rb[0]), "+v"(r.rb[1]), "+v"(r.rb[2]), "+v"(r.rb[3]) : : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]), "+v"(r.ra[4]), "+v"(r.ra[5]), "+v"(r.ra[6]), "+v"(r.ra[7]),
+                 "+v"(r.rb[0]), "+v"(r.rb[1]), "+v"(r.rb[2]), "+v"(r.rb[3]) : : "memory");
+}
+template <int FM, int FN> __device__ __forceinline__ void kpipe_init(KPipeRings<FM, FN>& r) {
+#pragma unroll
+  for (int i = 0; i < (FN == 5 ? 10 : 8); ++i) r.ra[i] = ig_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.rb[i] = ig_u32x4{0u, 0u, 0u, 0u};
 }
 
 // =====================================================================================================================
@@ -1330,6 +1399,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
 #endif
   const int nk = nchunk * 9, kt0 = c_begin * 9;
 
+#ifdef UR_HALO_DMA_BUILTIN                                  // A/B: the global_load_lds loaders of rounds 1-2
   auto issue_w = [&](int kt, int ring) {
     unsigned char* st = wring + ring * WBYTES;
 #pragma unroll
@@ -1348,6 +1418,33 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     const uint16_t* g = hpix[t] >= 0 ? src + hpix[t] * ld + cc : zero;
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(hbuf + (c & 1) * HBYTES + q * 1024), 16, 0, 0);
   };
+#else
+  // buffer-descriptor LDS-DMA (ig_lds_dma16): per piece one scalar M0 value, one lane offset kept in a register, one scalar K offset
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  const ig_u32x4 rs_w = ig_make_rsrc(Wt, (unsigned long long)p.Cout * p.ldw * 2);
+  const ig_u32x4 rs_x1 = ig_make_rsrc(X1, (unsigned long long)p.N * p.H * p.W * p.ldx * 2);
+  const ig_u32x4 rs_x2 = ig_make_rsrc(X2 ? X2 : X1, (unsigned long long)p.N * p.H * p.W * (X2 ? p.ldx2 : p.ldx) * 2);
+  const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring, hbuf_lds = (unsigned)(uintptr_t)(lptr_t)hbuf;
+  unsigned wvo[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) wvo[i] = woff[i] >= 0 ? (unsigned)woff[i] * 2u + chunk * 16u : IG_OOB;
+  auto issue_w = [&](int kt, int ring) {
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      const int qq = (wid_s + NW * i < WPIECES) ? wid_s + NW * i : wid_s;
+      ig_lds_dma16(wring_lds + ring * WBYTES + qq * 1024, wvo[i], rs_w, (unsigned)(kt0 + kt) * 128u);
+    }
+  };
+  auto issue_h = [&](int c, int t) {                                // halo piece (t*8 + wid) of chunk c
+    const int cb = (c_begin + c) * 64;                              // first channel of the chunk: decides the source (C1 % 64 == 0)
+    const bool second = cb >= p.C1;
+    const unsigned ld2 = (unsigned)(second ? p.ldx2 : p.ldx) * 2u;
+    const unsigned vo = hpix[t] >= 0 ? (unsigned)hpix[t] * ld2 + chunk * 16u : IG_OOB;
+    const unsigned m0v = hbuf_lds + (c & 1) * HBYTES + (t * NW + wid_s) * 1024;
+    if (second) ig_lds_dma16(m0v, vo, rs_x2, (unsigned)(cb - p.C1) * 2u);
+    else ig_lds_dma16(m0v, vo, rs_x1, (unsigned)cb * 2u);
+  };
+#endif
   // affine table of chunk c -> abuf[c & 1]: lanes 0-15 fetch a[64], lanes 16-31 b[64] (fp32), the rest a zero page.  Every
   // wave issues the same piece to the same place (identical bytes), so each may read it back after its OWN vmcnt and the
   // per-iteration DMA count stays wave-uniform.
@@ -1392,6 +1489,36 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
   }
   __builtin_amdgcn_s_barrier();
 
+  // LDS addresses (k-step 0) of the fragments tap tp of chunk cc reads: activation rows shifted by (dy, dx), weight ring slot tp % 3
+  auto tap_addr = [&](int cc, int tp, unsigned (&ab)[FM]) -> unsigned {
+    const int dy = tp / 3, dx = tp % 3;
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      const int hrow = (wm * FM + b + dy) * PW + dx + frow;
+      ab[b] = hb_lds + (cc & 1) * HBYTES + hrow * 128 + ((fhalf ^ ((hrow >> 1) & 7)) << 4);
+    }
+    return aw_lds + (tp % 3) * WBYTES;
+  };
+#if defined(UR_HALO_DMA_BUILTIN) || !defined(UR_HALO_STAGGER)     // (staggering measured no gain: DESIGN.md 6c)
+  constexpr bool stagger = false;
+  const bool early_grp = true;
+#else
+  constexpr bool stagger = ktile_asm_ok<FM, FN>();
+  const bool early_grp = wid_s < NW / 2;                   // (waves w and w + NW/2 share a SIMD)
+#endif
+#if UR_HALO_ABL == 6
+  unsigned long long ts[63];
+#pragma unroll
+  for (int i = 0; i < 63; ++i) ts[i] = 0;
+#endif
+  KPipeRings<FM, FN> rings;
+  if constexpr (ktile_asm_ok<FM, FN>()) {
+    kpipe_init(rings);
+    unsigned ab0[FM];
+    const unsigned aw0 = tap_addr(0, 0, ab0);
+    kpipe<FM, FN, F16, 0>(acc, rings, ab0, aw0, ab0, aw0);
+  }
+
   // K loop as chunks x 9 UNROLLED taps: the tap decides everything that used to be run-time control in the loop body (which
   // halo piece to prefetch, the fragment row offset, the weight-ring slot = tap % 3 because 9 % 3 == 0), so each tap's body
   // is straight-line code with immediate LDS offsets instead of a branch ladder in front of every 20 MFMAs.
@@ -1403,24 +1530,58 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
       const int kt = c * 9 + tap;
       const bool more_w = kt + 2 < nk;
       const bool more_h = tap < HSLOTS && next_chunk;
-      if (more_w) issue_w(kt + 2, (tap + 2) % 3);
-      if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
+      // The DMA path of a CU takes ~24 cycles per 1-KiB piece and a wave sits in its buffer_load until the queue has room: with all
+      // eight waves issuing at the top of the tap nobody feeds the matrix pipe meanwhile (0.37 us of a 1.2 us tap, UR_HALO_ABL=5).
+      // So the two waves of a SIMD issue half a tap apart: waves 0..NW/2-1 here, the others between the two MFMA halves.
+      auto issue_tap = [&]() {
+#if UR_HALO_ABL != 5                                        // (5: timing-only, no DMA in the loop at all)
+        if (more_w) issue_w(kt + 2, (tap + 2) % 3);
+        if (tap < HSLOTS) { if (next_chunk) issue_h(c + 1, tap < HSLOTS ? tap : 0); }
+#endif
+      };
+#if UR_HALO_ABL == 6                                        // in-kernel phase timers (shader cycles) of chunk 1, workgroup 0, waves 0 and NW/2
+#define IG_TS(i) do { if (c == 1) ts[tap * 7 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define IG_TS(i) do { } while (0)
+#endif
+      IG_TS(0);
+      if (!stagger || early_grp) issue_tap();
+      IG_TS(1);
       const bool ab_now = gnp && tap == 0 && next_chunk;    // (+1 DMA op in this iteration, counted in the wait below)
       if (ab_now) issue_ab(c + 1);
       // piece (tap - 2) of the next chunk landed with the previous iteration's wait: normalise it in LDS next to this tap's MFMAs
       // (splitting the two waves of a SIMD to opposite sides of the MFMA block measured no gain and cost registers)
       if (gnp && tap >= 2 && tap - 2 < HSLOTS && next_chunk) gn_slot(c + 1, (tap >= 2 && tap - 2 < HSLOTS) ? tap - 2 : 0);
-      if constexpr (ktile_asm_ok<FM, FN>()) {
-        const int dy = tap / 3, dx = tap % 3;
-        unsigned ab[FM];
-#pragma unroll
-        for (int b = 0; b < FM; ++b) {
-          const int hrow = (wm * FM + b + dy) * PW + dx + frow;
-          ab[b] = hb_lds + (c & 1) * HBYTES + hrow * 128 + ((fhalf ^ ((hrow >> 1) & 7)) << 4);
-        }
-#if UR_HALO_ABL != 2                                        // (2: timing-only, no MFMA body)
-        ktile_mma<FM, FN, F16>(acc, ab, aw_lds + (tap % 3) * WBYTES);
+      // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
+      auto dma_wait = [&]() {
+#if UR_HALO_ABL != 1 && UR_HALO_ABL != 5                    // (1: timing-only, never wait for the DMA)
+        if (ab_now) {                                       // tap 0 with the next chunk's affine table in flight as well
+          if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
+        else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+        else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+      };
+      if constexpr (ktile_asm_ok<FM, FN>()) {
+        // hand-scheduled, tap-crossing pipeline (kpipe above).  Barrier 1 (mid-tap) publishes weight tile kt + 1 and every halo /
+        // GroupNorm piece of earlier taps - the second half prefetches the next tap's first fragments behind it; barrier 2 (end)
+        // tells everyone this tap's weight tile has been read: its ring slot is the next tap's DMA target.  This tap's own reads
+        // are retired by then (its MFMAs consumed them); the in-place GroupNorm writes are older than those reads (LDS is in-order).
+        unsigned ab[FM], abn[FM];
+        const unsigned aw = tap_addr(c, tap, ab), awn = tap_addr(c + (tap == 8 ? 1 : 0), (tap + 1) % 9, abn);
+        kpipe<FM, FN, F16, 1>(acc, rings, ab, aw, abn, awn);
+        IG_TS(2);
+        if (stagger && !early_grp) issue_tap();
+        dma_wait();
+        IG_TS(3);
+        __builtin_amdgcn_s_barrier();
+        IG_TS(4);
+        kpipe<FM, FN, F16, 2>(acc, rings, ab, aw, abn, awn);      // (the last tap prefetches too - valid LDS, never used: one code path)
+        IG_TS(5);
+        __builtin_amdgcn_s_barrier();
+        IG_TS(6);
       } else {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned char* wsm = wring + (tap % 3) * WBYTES;
@@ -1448,31 +1609,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
             for (int b = 0; b < FM; ++b)
               acc[a][b] = mfma16t(afr[a], bfr[b], acc[a][b]);
         }
+        dma_wait();
+        // lgkmcnt(0): (1) this wave's fragment reads of the ring slot / halo buffer that the NEXT tap's DMA overwrites are retired
+        // before anyone passes the barrier (hipcc leaves the last reads outstanding across it otherwise - see igemm_glds_kernel);
+        // (2) the in-place GroupNorm writes are published by the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       }
-      // everything issued in EARLIER iterations has landed once only this iteration's pieces may still be in flight
-#if UR_HALO_ABL == 1                                        // timing-only: never wait for the DMA
-      if (false) {
-#else
-      if (ab_now) {                                       // tap 0 with the next chunk's affine table in flight as well
-#endif
-        if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      }
-#if UR_HALO_ABL != 1
-      else if (more_w && more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
-      else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-      else if (more_h) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-      // lgkmcnt(0): (1) this wave's fragment reads of the ring slot / halo buffer that the NEXT tap's DMA overwrites are retired
-      // before anyone passes the barrier (hipcc leaves the last reads outstanding across it otherwise - see igemm_glds_kernel);
-      // (2) the in-place GroupNorm writes are published by the barrier
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
     }
   }
+  if constexpr (ktile_asm_ok<FM, FN>()) kpipe_drain(rings);      // the last tap's prefetch lands in the rings: they stay reserved until here
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // last MFMA of the asm tap body -> VALU reads of the accumulators
-#if UR_HALO_ABL == 4                                          // timing-only: no epilogue (one store keeps the loop alive)
+#if UR_HALO_ABL == 6                                          // phase timers -> the first bytes of y (no epilogue)
+  if (acc[0][0][0] == 123.456f) reinterpret_cast<uint16_t*>(p.y)[0] = 1;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wid == 0 || wid == NW / 2)) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y) + (wid ? 64 : 0);
+#pragma unroll
+    for (int i = 0; i < 63; ++i) o[i] = ts[i];
+  }
+#elif UR_HALO_ABL == 4                                        // timing-only: no epilogue (one store keeps the loop alive)
   if (acc[0][0][0] == 123.456f) reinterpret_cast<uint16_t*>(p.y)[0] = 1;
 #else
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
