@@ -1634,6 +1634,286 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised form of igemm_halo_kernel: NW compute waves + ONE loader wave.
+// Phase timers in the kernel above (profiles/r3_halo_phase_timers.txt) show where the matrix pipe idles: a CU's DMA path takes
+// ~25 cycles per 1-KiB piece and a wave sits in its buffer_load until the queue accepts it, so with every wave issuing its
+// share at the top of a tap the first MFMA starts 400-660 cycles late (of ~2100), whatever the order or the instruction count.
+// Here the compute waves never execute a memory instruction inside the K loop: the loader wave issues all pieces (half of the
+// weight tile + the tap's halo pieces before the mid-tap barrier, the other half behind it), waits with a counted vmcnt for the
+// previous tap's pieces and takes part in the two barriers, which publish them.  It always issues the same number of pieces per
+// tap position (tile / chunk indices clamped at the end: a re-fetch into a slot nobody reads), so its counts are immediates.
+template <int TH, int BN, int WM, int WN, bool F16, bool GNP>
+__global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const ConvK p) {
+  constexpr int NW = WM * WN, TW = 32, BM = TH * TW, PW = TW + 2, HPIX = (TH + 2) * PW;
+  constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW), HNEED = (HPIX + 7) / 8;          // (LDS layout of the plain kernel); pieces actually read
+  constexpr int HPIECES = HSLOTS * NW, HBYTES = HPIECES * 1024;
+  // The loader spreads a chunk's HNEED patch pieces over the 16 half-taps of taps 0..7 of the previous chunk (HPER per half-tap:
+  // a patch piece costs the loader ~85 cycles, a weight piece ~38 - profiles/r3_halo_phase_timers.txt - so each half-tap carries
+  // about as much issue time as its 10 MFMAs per wave take); tap 8 carries none (its pieces would land after the prefetch).
+  constexpr int HPER = (HNEED + 15) / 16, HTAP = 2 * HPER;
+  constexpr int WBYTES = BN * 128, WPIECES = BN / 8, WH = WPIECES / 2;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = NW * 64;
+  static_assert(NW == 8 && WTM % 32 == 0 && WTN % 32 == 0 && HTAP <= NW && ktile_asm_ok<FM, FN>(), "wave layout");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const hbuf = smem;                      // 2 halo patches
+  unsigned char* const wring = smem + 2 * HBYTES;        // 3 weight tiles
+  unsigned char* const abuf = wring + 3 * WBYTES;        // 2 x 1 KiB: GroupNorm affine (a[64] | b[64]) of the current / next chunk
+  constexpr bool gnp = GNP;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+#if UR_HALO_ABL == 7                                          // workgroup time line in 100 MHz ticks (A/B build): start, K loop, end
+  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  const int sz = blockIdx.y;
+  int id = blockIdx.x;
+  {
+    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = id % p.tiles_n, tmi = id / p.tiles_n;
+  const int tiles_x = p.OW / TW, tiles_y = p.OH / TH;
+  const int tx = tmi % tiles_x, ty = (tmi / tiles_x) % tiles_y, img = tmi / (tiles_x * tiles_y);
+  const int n0 = tn * BN;
+  const int m0 = img * p.OHW + ty * TH * p.OW + tx * TW;         // first output pixel of the patch
+  const int cps = p.nk_per_split / 9, c_begin = sz * cps, nchunk = min(p.nk / 9, c_begin + cps) - c_begin;
+  const int nk = nchunk * 9, kt0 = c_begin * 9;
+  const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring, hbuf_lds = (unsigned)(uintptr_t)(lptr_t)hbuf;
+  const unsigned abuf_lds = (unsigned)(uintptr_t)(lptr_t)abuf;
+  const int lr = lane >> 3, ps = lane & 7;
+  // halo row hr of the patch -> this lane's input pixel (or -1: zero padding / surplus row)
+  auto halo_pixel = [&](int hr) -> int {
+    const int hy = hr / PW, hx = hr - hy * PW;
+    int iy = ty * TH - 1 + hy, ix = tx * TW - 1 + hx;               // coordinates in the (possibly upsampled) input
+    const bool v = hr < HPIX && (unsigned)iy < (unsigned)p.OH && (unsigned)ix < (unsigned)p.OW;
+    if (p.ups) { iy >>= 1; ix >>= 1; }
+    return v ? (img * p.H + iy) * p.W + ix : -1;
+  };
+
+  if (wid_s == NW) {
+    // ================================================= loader wave ==================================================
+    // piece q = LDS rows 8q .. 8q+7; the lane's physical 16-byte slot ps holds logical K chunk ps ^ ((row >> 1) & 7): two parities
+    const unsigned ck0 = (ps ^ ((lr >> 1) & 7)) * 16u, ck1 = (ps ^ ((4 + (lr >> 1)) & 7)) * 16u;
+    const ig_u32x4 rs_w = ig_make_rsrc(p.w, (unsigned long long)p.Cout * p.ldw * 2);
+    const ig_u32x4 rs_x1 = ig_make_rsrc(p.x, (unsigned long long)p.N * p.H * p.W * p.ldx * 2);
+    const ig_u32x4 rs_x2 = ig_make_rsrc(p.x2 ? p.x2 : p.x, (unsigned long long)p.N * p.H * p.W * (p.x2 ? p.ldx2 : p.ldx) * 2);
+    const ig_u32x4 rs_ab = ig_make_rsrc(gnp ? (const void*)p.gn_ab : (const void*)p.w, gnp ? (unsigned long long)p.N * 2 * p.Cin * 4 : 16ull);
+    unsigned wvo[WPIECES];
+#pragma unroll
+    for (int q = 0; q < WPIECES; ++q) {
+      const int row = n0 + q * 8 + lr;
+      wvo[q] = row < p.Cout ? (unsigned)row * (unsigned)p.ldw * 2u + ((q & 1) ? ck1 : ck0) : IG_OOB;
+    }
+    int hpx[HNEED];
+    auto dma_w = [&](int kt, int ring, int q0, int q1) {            // pieces [q0, q1) of weight tile kt (clamped) -> ring slot
+      const unsigned so = (unsigned)(kt0 + min(kt, nk - 1)) * 128u;
+#pragma unroll
+      for (int q = q0; q < q1; ++q) ig_lds_dma16(wring_lds + ring * WBYTES + q * 1024, wvo[q], rs_w, so);
+    };
+    auto dma_h = [&](int c, int h) {                                // patch pieces of half-tap h (0..15), chunk c (clamped) -> halo buffer c & 1
+      const int cb = (c_begin + min(c, nchunk - 1)) * 64;           // first channel of the chunk: decides the source (C1 % 64 == 0)
+      const bool second = cb >= p.C1;
+      const unsigned ld2 = (unsigned)(second ? p.ldx2 : p.ldx) * 2u;
+      const unsigned so = (unsigned)(second ? cb - p.C1 : cb) * 2u;
+#pragma unroll
+      for (int j = 0; j < HPER; ++j) {
+        const int q = h * HPER + j;
+        if (h < 16 && q < HNEED) {
+          const unsigned vo = hpx[q] >= 0 ? (unsigned)hpx[q] * ld2 + ((q & 1) ? ck1 : ck0) : IG_OOB;
+          const unsigned m0v = hbuf_lds + (c & 1) * HBYTES + q * 1024;
+          if (second) ig_lds_dma16(m0v, vo, rs_x2, so);
+          else ig_lds_dma16(m0v, vo, rs_x1, so);
+        }
+      }
+    };
+    auto halo_count = [](int h) -> int { return (h >= 16 || h * HPER >= HNEED) ? 0 : (HNEED - h * HPER < HPER ? HNEED - h * HPER : HPER); };
+    auto dma_ab = [&](int c) {                                      // affine table of chunk c: lanes 0-15 a[64], 16-31 b[64] (fp32)
+      const unsigned vo = lane < 32 ? (unsigned)((img * 2 + (lane >> 4 & 1)) * p.Cin + (lane & 15) * 4) * 4u : IG_OOB;
+      ig_lds_dma16(abuf_lds + (c & 1) * 1024, vo, rs_ab, (unsigned)((c_begin + min(c, nchunk - 1)) * 64) * 4u);
+    };
+#if UR_HALO_ABL == 6
+    unsigned long long lts[45];
+#pragma unroll
+    for (int i = 0; i < 45; ++i) lts[i] = 0;
+#define LD_TS(i) do { if (c == 1) lts[tap * 5 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LD_TS(i) do { } while (0)
+#endif
+    // Prologue: the compute waves fetch patch 0 and weight tile 0 themselves (nine waves feed the DMA path 2-3x faster than one, and
+    // they have nothing else to do yet); the loader issues the affine table and weight tile 1 - which its own tap-0 wait covers - and
+    // builds its pixel table while those fly.
+    if (gnp) dma_ab(0);
+    dma_w(1, 1, 0, WPIECES);
+#pragma unroll
+    for (int q = 0; q < HNEED; ++q) hpx[q] = halo_pixel(q * 8 + lr);
+    if (gnp) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPIECES) : "memory");      // the table is in (tile 1 may still fly)
+    __builtin_amdgcn_s_barrier();
+    if (gnp) __builtin_amdgcn_s_barrier();                              // (the compute waves normalise patch 0 in between)
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kt = c * 9 + tap;
+        LD_TS(0);
+        dma_w(kt + 2, (tap + 2) % 3, 0, WH);
+        dma_h(c + 1, 2 * tap);
+        if (gnp && tap == 0) dma_ab(c + 1);
+        LD_TS(1);
+        // everything issued in EARLIER taps has landed once only this tap's first half may still be in flight
+        if (kt + 1 == nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // last tap: nothing may land behind the barrier (the epilogue reuses LDS)
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WH + halo_count(2 * tap) + ((gnp && tap == 0) ? 1 : 0)) : "memory");
+        LD_TS(2);
+        __builtin_amdgcn_s_barrier();
+        LD_TS(3);
+        if (kt + 1 < nk) { dma_w(kt + 2, (tap + 2) % 3, WH, WPIECES); dma_h(c + 1, 2 * tap + 1); }
+        LD_TS(4);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+#if UR_HALO_ABL == 6
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y) + 128;
+#pragma unroll
+      for (int i = 0; i < 45; ++i) o[i] = lts[i];
+    }
+#endif
+    return;
+  }
+
+  // =================================================== compute waves ==================================================
+  const int wm = wid % WM, wn = wid / WM;
+  // GroupNorm apply (+ SiLU) of the input, in place in LDS: the pieces the loader issued during tap t (HTAP of them, piece
+  // t * HTAP + wid for wave wid < HTAP) were published by the barriers of tap t + 1 and are rewritten at the top of tap t + 2.
+  const int chunk = ps ^ ((((wid & 1) << 2) + (lr >> 1)) & 7);      // (HTAP is even: the pieces of a wave share the parity of wid)
+  static_assert(HTAP % 2 == 0, "piece parity");
+  int hpix[8];                                            // (GNP: kept for the whole kernel; otherwise only for the prologue fetch below)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) hpix[t] = (wid < HTAP && t * HTAP + wid < HNEED) ? halo_pixel((t * HTAP + wid) * 8 + lr) : -1;
+  {
+    // prologue fetch: patch 0 (piece t * HTAP + wid, waves < HTAP) and weight tile 0 (pieces wid, wid + NW, ..) - see the loader
+    const ig_u32x4 rs_w = ig_make_rsrc(p.w, (unsigned long long)p.Cout * p.ldw * 2);
+    const int cb = c_begin * 64;
+    const bool second = cb >= p.C1;
+    const ig_u32x4 rs_x = second ? ig_make_rsrc(p.x2, (unsigned long long)p.N * p.H * p.W * p.ldx2 * 2) : ig_make_rsrc(p.x, (unsigned long long)p.N * p.H * p.W * p.ldx * 2);
+    const unsigned ld2 = (unsigned)(second ? p.ldx2 : p.ldx) * 2u, so = (unsigned)(second ? cb - p.C1 : cb) * 2u;
+    if (wid_s < HTAP) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t * HTAP + wid_s < HNEED)
+          ig_lds_dma16(hbuf_lds + (t * HTAP + wid_s) * 1024, hpix[t] >= 0 ? (unsigned)hpix[t] * ld2 + chunk * 16u : IG_OOB, rs_x, so);
+    }
+#pragma unroll
+    for (int j = 0; j < (WPIECES + NW - 1) / NW; ++j) {
+      const int q = wid_s + NW * j;
+      if (q < WPIECES) {
+        const int row = n0 + q * 8 + lr;
+        ig_lds_dma16(wring_lds + q * 1024, row < p.Cout ? (unsigned)row * (unsigned)p.ldw * 2u + chunk * 16u : IG_OOB, rs_w, (unsigned)kt0 * 128u);
+      }
+    }
+  }
+  auto gn_slot = [&](int c, int t) {                      // this wave's piece of the ones issued in tap t, chunk c's patch
+    if (hpix[t] >= 0)
+      gn_piece_inplace<F16>(hbuf + (c & 1) * HBYTES + (t * HTAP + wid) * 1024 + lane * 16, gn_load_ab(abuf + (c & 1) * 1024, chunk), p.gn_silu != 0);
+  };
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const unsigned aw_lds = wring_lds + (wn * WTN + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  static_assert(((WTN >> 1) & 7) == 0, "the wave's weight rows must keep the swizzle phase of fragment row 0");
+  // LDS addresses (k-step 0) of the fragments tap tp of chunk cc reads: activation rows shifted by (dy, dx), weight ring slot tp % 3
+  auto tap_addr = [&](int cc, int tp, unsigned (&ab)[FM]) -> unsigned {
+    const int dy = tp / 3, dx = tp % 3;
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      const int hrow = (wm * FM + b + dy) * PW + dx + frow;
+      ab[b] = hbuf_lds + (cc & 1) * HBYTES + hrow * 128 + ((fhalf ^ ((hrow >> 1) & 7)) << 4);
+    }
+    return aw_lds + (tp % 3) * WBYTES;
+  };
+#if UR_HALO_ABL == 6
+  unsigned long long ts[45];
+#pragma unroll
+  for (int i = 0; i < 45; ++i) ts[i] = 0;
+#define WS_TS(i) do { if (c == 1) ts[tap * 5 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_TS(i) do { } while (0)
+#endif
+  KPipeRings<FM, FN> rings;
+  kpipe_init(rings);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of patch 0 / weight tile 0
+  __builtin_amdgcn_s_barrier();                           // ... and everybody else's (+ the loader's affine table)
+  if (gnp) {                                              // chunk 0's patch is normalised before anyone reads it
+#pragma unroll
+    for (int t = 0; t < 8; ++t) gn_slot(0, t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  {
+    unsigned ab0[FM];
+    const unsigned aw0 = tap_addr(0, 0, ab0);
+    kpipe<FM, FN, F16, 0>(acc, rings, ab0, aw0, ab0, aw0);
+  }
+#if UR_HALO_ABL == 6
+  const unsigned long long loop_c0 = __builtin_readcyclecounter(), loop_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if UR_HALO_ABL == 7
+  const unsigned long long wg_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int c = 0; c < nchunk; ++c) {
+    const bool next_chunk = c + 1 < nchunk;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // the pieces issued two taps ago were published by the previous tap's barriers: normalise them next to this tap's MFMAs
+      // (tap 0: the ones of tap 7 of the previous chunk - this chunk's own patch, first read by its tap 6)
+      if (gnp && tap >= 2 && next_chunk) gn_slot(c + 1, tap >= 2 ? tap - 2 : 0);
+      if (gnp && tap == 0 && c > 0) gn_slot(c, 7);
+      unsigned ab[FM], abn[FM];
+      const unsigned aw = tap_addr(c, tap, ab), awn = tap_addr(c + (tap == 8 ? 1 : 0), (tap + 1) % 9, abn);
+      WS_TS(0);
+      kpipe<FM, FN, F16, 1>(acc, rings, ab, aw, abn, awn);
+      WS_TS(1);
+      __builtin_amdgcn_s_barrier();                       // weight tile kt + 1 (and every older piece) is in LDS
+      WS_TS(2);
+      kpipe<FM, FN, F16, 2>(acc, rings, ab, aw, abn, awn);
+      WS_TS(3);
+      __builtin_amdgcn_s_barrier();                       // everyone has read weight tile kt: its slot takes tile kt + 3
+      WS_TS(4);
+    }
+  }
+  kpipe_drain(rings);
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // last MFMA of the asm tap body -> VALU reads of the accumulators
+#if UR_HALO_ABL == 6                                          // phase timers -> the first bytes of y (no epilogue)
+  if (acc[0][0][0] == 123.456f) reinterpret_cast<uint16_t*>(p.y)[0] = 1;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wid == 0 || wid == NW / 2)) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y) + (wid ? 64 : 0);
+#pragma unroll
+    for (int i = 0; i < 45; ++i) o[i] = ts[i];
+  }
+  if (lane == 0 && wid == 0 && blockIdx.x < 256) {            // K-loop duration of every workgroup in shader cycles and in 100 MHz ticks
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y) + 256 + 2 * blockIdx.x;
+    o[0] = __builtin_readcyclecounter() - loop_c0;
+    o[1] = __builtin_amdgcn_s_memrealtime() - loop_r0;
+  }
+#elif UR_HALO_ABL == 7
+  const unsigned long long wg_t2 = __builtin_amdgcn_s_memrealtime();
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && wid == 0 && blockIdx.x < 256 && blockIdx.y == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y) + 4 * blockIdx.x;
+    o[0] = wg_t0; o[1] = wg_t1; o[2] = wg_t2; o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#else
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+#endif
+}
+
 template <int TH, int BN, int WM, int WN>
 int launch_halo(ConvK& k, hipStream_t s) {
   constexpr int NW = WM * WN, BM = TH * 32, HPIX = (TH + 2) * 34, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
@@ -1664,10 +1944,18 @@ int launch_halo(ConvK& k, hipStream_t s) {
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_ws_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_ws_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
-  else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
+  static const bool no_ws = getenv("UR_HALO_NOWS") != nullptr;          // A/B: every wave loads for itself (rounds 1-2 structure)
+  if (no_ws) {
+    if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
+    else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
+  } else {
+    if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_ws_kernel<TH, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3((NW + 1) * 64), lds, s, k));
+    else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_ws_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3((NW + 1) * 64), lds, s, k));
+  }
   if (k.splitk > 1) {
     k.patch_tw = 0;                                        // the partial planes are plain [M][Cout]
     launch_splitk_reduce(k, s);
