@@ -229,7 +229,7 @@ def write(out):
     txt += ktile("IG_ASM_KT_1x4", 1, 4, 8)
     txt += ktile("IG_ASM_KT_4x1", 4, 1, 8)
     txt += ktile_pipe("IG_ASM_KP_1x5", 1, 5, 10, 4, 10)
-    txt += ktile_pipe("IG_ASM_KP_2x2", 2, 2, 8, 4, 8)
+    txt += ktile_pipe("IG_ASM_KP_2x2", 2, 2, 4, 4, 8)
     open(out, "w").write(txt)
     print("wrote", os.path.normpath(out))
 

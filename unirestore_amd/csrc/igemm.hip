@@ -108,7 +108,7 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   }
   static const bool no_g256 = getenv("UR_IGEMM_NOG256") != nullptr;
   if (!no_g256 && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.staged_ok_ && k.Cout % 256 == 0 && !k.yt && (k.act == UR_ACT_GEGLU || k.act == UR_ACT_GATE) &&
-      (long long)((k.M + 255) / 256) * (k.Cout / 256) * k.nbatch >= 200 && (long long)k.M * k.ldx < (1ll << 31))
+      (long long)((k.M + 255) / 256) * (k.Cout / 256) * k.nbatch >= 200 && (long long)k.M * k.ldx < (1ll << 31) - 256)
   {
     // 320-wide tiles when they land on whole rounds of CUs (2048 x 10240: 8 x 32 = 256 tiles instead of 320)
     static const bool no_g320 = getenv("UR_IGEMM_NOG320") != nullptr;
@@ -126,7 +126,7 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   // pure GEMMs that will not be split: the LDS-DMA twin of the register-staged kernel (no staging registers / ds_writes)
   static const bool g1dma = getenv("UR_IGEMM_NOG1DMA") == nullptr;
   const bool g1 = g1dma && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.pad_t == 0 && k.pad_l == 0 && k.OH == k.H && k.OW == k.W &&
-                  (long long)k.M * k.ldx + k.Ktot < (1ll << 31);
+                  (long long)k.M * k.ldx + k.Ktot < (1ll << 31) - 256;
 #ifdef UR_AB_VARIANTS
   if (const char* ab = getenv("UR_AB_ID")) if (g1 && !pair && !k.f16 && atoi(ab) >= 0) return urk::g1_ab_bf16(&k, s, atoi(ab));
 #endif

@@ -1029,6 +1029,28 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
 }
 
+typedef uint32_t ig_u32x4 __attribute__((ext_vector_type(4)));
+// LDS-DMA of one 1-KiB piece (64 lanes x 16 bytes -> LDS bytes [m0v, m0v + 1024)) through a raw buffer descriptor: lane address =
+// base + voff + soff, and a lane whose voff is past num_records reads ZERO - the convolution's zero padding, ragged Cout rows and
+// the K tail cost no select, no zero page and no 64-bit address arithmetic (the global_load_lds form needed ~10 VALU + a
+// v_readfirstlane for M0 per piece: ~45 instructions per tap and wave in front of the MFMAs, 27 % of the dominant conv launch).
+// Invisible to hipcc's s_waitcnt bookkeeping: the callers count vmcnt themselves (they did before, too).
+constexpr unsigned IG_OOB = 0xffffff00u;       // voffset of a lane that must read zeros (>= every num_records used here)
+__device__ __forceinline__ ig_u32x4 ig_make_rsrc(const void* base, unsigned long long bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  ig_u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);         // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((unsigned)(bytes < IG_OOB ? bytes : IG_OOB));
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void ig_lds_dma16(unsigned m0v, unsigned voff, const ig_u32x4& rs, unsigned soff) {
+  // (readfirstlane: free when hipcc already knows the value is wave-uniform, and keeps an "s" operand out of a VGPR when it does not)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(rs),
+               "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+
 // Pure-GEMM specialisation of the LDS-DMA ring (1x1 / Linear, single source): row base offsets are 32-bit element
 // offsets and nothing else is kept per row, which leaves room for 256 x 256 tiles (128 accumulator registers per wave).
 // Large-N GEMMs (GEGLU, fused QKV) are L2->CU ingest bound: at 128 x 128 tiles every flop costs 1/64 B of ingest,
@@ -1056,14 +1078,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
   const int lrow = tid >> 3;
   const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  int kbase = 0;
+#ifdef UR_GEMM_DMA_BUILTIN                                  // A/B: the global_load_lds loader of rounds 1-2
   int xoff[XP], woff[WP];
 #pragma unroll
   for (int i = 0; i < XP; ++i) { const int m = m0 + i * RPP + lrow; xoff[i] = m < p.M ? m * p.ldx + chunk * 8 : -1; }
 #pragma unroll
   for (int j = 0; j < WP; ++j) { const int r = n0 + j * RPP + lrow; woff[j] = r < p.Cout ? r * p.ldw + chunk * 8 : -1; }
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  int kbase = 0;
   auto issue_tile = [&](int stage) {
     unsigned char* xs = smem + stage * STAGE;
     unsigned char* wsm = xs + BM * 128;
@@ -1080,6 +1103,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
     }
     kbase += 64;
   };
+#else
+  // buffer-descriptor LDS-DMA (ig_lds_dma16): rows past M / Cout read zero through the range check, the K tail through one select
+  const ig_u32x4 rs_x = ig_make_rsrc(X1, (unsigned long long)p.M * p.ldx * 2);
+  const ig_u32x4 rs_w = ig_make_rsrc(Wt, (unsigned long long)p.Cout * p.ldw * 2);
+  const unsigned smem_lds = (unsigned)(uintptr_t)(lptr_t)smem;
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  unsigned xvo[XP], wvo[WP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) { const int m = m0 + i * RPP + lrow; xvo[i] = m < p.M ? ((unsigned)m * (unsigned)p.ldx + chunk * 8u) * 2u : IG_OOB; }
+#pragma unroll
+  for (int j = 0; j < WP; ++j) { const int r = n0 + j * RPP + lrow; wvo[j] = r < p.Cout ? ((unsigned)r * (unsigned)p.ldw + chunk * 8u) * 2u : IG_OOB; }
+  auto issue_tile = [&](int stage) {
+    const unsigned xs = smem_lds + stage * STAGE, wsm = xs + BM * 128;
+    const bool kval = kbase + chunk * 8 < p.Ktot;
+    const unsigned so = (unsigned)kbase * 2u;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) ig_lds_dma16(xs + (i * RPP + wid_s * 8) * 128, kval ? xvo[i] : IG_OOB, rs_x, so);
+#pragma unroll
+    for (int j = 0; j < WP; ++j) ig_lds_dma16(wsm + (j * RPP + wid_s * 8) * 128, kval ? wvo[j] : IG_OOB, rs_w, so);
+    kbase += 64;
+  };
+#endif
   f32x16 acc[FN][FM];
 #pragma unroll
   for (int a = 0; a < FN; ++a)
@@ -1221,7 +1266,6 @@ __device__ __forceinline__ void gn_piece_inplace(unsigned char* piece, const GnA
 #ifndef UR_HALO_ABL
 #define UR_HALO_ABL 0      // timing-only ablations of igemm_halo_kernel (A/B builds): 1 = no DMA waits, 2 = no MFMA body
 #endif
-typedef uint32_t ig_u32x4 __attribute__((ext_vector_type(4)));
 #define IG_MN(ASM, ...)                                                                      \
   do {                                                                                       \
     if constexpr (F16) asm volatile(ASM("v_mfma_f32_32x32x16_f16") __VA_ARGS__);             \
@@ -1243,27 +1287,6 @@ __device__ __forceinline__ void ktile_mma(f32x16 (&acc)[FN][FM], const unsigned 
     static_assert(FM == 0, "no hand-scheduled K tile for this fragment shape");
   }
 }
-// LDS-DMA of one 1-KiB piece (64 lanes x 16 bytes -> LDS bytes [m0v, m0v + 1024)) through a raw buffer descriptor: lane address =
-// base + voff + soff, and a lane whose voff is past num_records reads ZERO - the convolution's zero padding, ragged Cout rows and
-// the K tail cost no select, no zero page and no 64-bit address arithmetic (the global_load_lds form needed ~10 VALU + a
-// v_readfirstlane for M0 per piece: ~45 instructions per tap and wave in front of the MFMAs, 27 % of the dominant conv launch).
-// Invisible to hipcc's s_waitcnt bookkeeping: the callers count vmcnt themselves (they did before, too).
-constexpr unsigned IG_OOB = 0xffffff00u;       // voffset of a lane that must read zeros (>= every num_records used here)
-__device__ __forceinline__ ig_u32x4 ig_make_rsrc(const void* base, unsigned long long bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  ig_u32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
-  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);         // stride 0: raw buffer
-  r[2] = __builtin_amdgcn_readfirstlane((unsigned)(bytes < IG_OOB ? bytes : IG_OOB));
-  r[3] = 0x00020000u;
-  return r;
-}
-__device__ __forceinline__ void ig_lds_dma16(unsigned m0v, unsigned voff, const ig_u32x4& rs, unsigned soff) {
-  // (readfirstlane: free when hipcc already knows the value is wave-uniform, and keeps an "s" operand out of a VGPR when it does not)
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(rs),
-               "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
-}
-
 template <int FM, int FN> constexpr bool ktile_asm_ok() {
 #ifdef UR_IGEMM_NOASM
   return false;
@@ -1277,7 +1300,7 @@ template <int FM, int FN> constexpr bool ktile_asm_ok() {
 // with the workgroup's "next weight tile landed" wait + barrier between them; PHASE 0 issues the first tile's prefetch.  The
 // fragment rings ra / rb live across the blocks.  Without it the matrix pipe drains at every per-tile barrier: the first MFMA
 // behind the barrier waits a full LDS round trip (~150-250 of ~1300 cycles per tile, tools/probe + UR_IGASM_ABL timings).
-template <int FM, int FN> struct KPipeRings { ig_u32x4 ra[FN == 5 ? 10 : 8], rb[4]; };
+template <int FM, int FN> struct KPipeRings { ig_u32x4 ra[FN == 5 ? 10 : 4], rb[4]; };      // (ring sizes of tools/gen_igemm_asm.py)
 template <int FM, int FN, bool F16, int PHASE>
 __device__ __forceinline__ void kpipe(f32x16 (&acc)[FN][FM], KPipeRings<FM, FN>& r, const unsigned (&ab)[FM], unsigned aw, const unsigned (&abn)[FM],
                                       unsigned awn) {
@@ -1286,7 +1309,7 @@ __device__ __forceinline__ void kpipe(f32x16 (&acc)[FN][FM], KPipeRings<FM, FN>&
       "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]), "+v"(r.ra[4]), "+v"(r.ra[5]), "+v"(r.ra[6]), "+v"(r.ra[7]), "+v"(r.ra[8]), "+v"(r.ra[9]), \
       "+v"(r.rb[0]), "+v"(r.rb[1]), "+v"(r.rb[2]), "+v"(r.rb[3]), "=&v"(x0), "=&v"(xw) : "v"(ab[0]), "v"(aw), "v"(abn[0]), "v"(awn) : "memory"
 #define KP_OPS_2x2 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),                                                          \
-      "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]), "+v"(r.ra[4]), "+v"(r.ra[5]), "+v"(r.ra[6]), "+v"(r.ra[7]),                       \
+      "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]),                                                                                 \
       "+v"(r.rb[0]), "+v"(r.rb[1]), "+v"(r.rb[2]), "+v"(r.rb[3]), "=&v"(x0), "=&v"(x1), "=&v"(xw)                                                   \
       : "v"(ab[0]), "v"(ab[1]), "v"(aw), "v"(abn[0]), "v"(abn[1]), "v"(awn) : "memory"
   if constexpr (FM == 1 && FN == 5) {
@@ -1310,12 +1333,11 @@ template <int FM, int FN> __device__ __forceinline__ void kpipe_drain(KPipeRings
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]), "+v"(r.ra[4]), "+v"(r.ra[5]), "+v"(r.ra[6]), "+v"(r.ra[7]),
                  "+v"(r.ra[8]), "+v"(r.ra[9]), "+v"(r.rb[0]), "+v"(r.rb[1]), "+v"(r.rb[2]), "+v"(r.rb[3]) : : "memory");
   else
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]), "+v"(r.ra[4]), "+v"(r.ra[5]), "+v"(r.ra[6]), "+v"(r.ra[7]),
-                 "+v"(r.rb[0]), "+v"(r.rb[1]), "+v"(r.rb[2]), "+v"(r.rb[3]) : : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.ra[0]), "+v"(r.ra[1]), "+v"(r.ra[2]), "+v"(r.ra[3]), "+v"(r.rb[0]), "+v"(r.rb[1]), "+v"(r.rb[2]), "+v"(r.rb[3]) : : "memory");
 }
 template <int FM, int FN> __device__ __forceinline__ void kpipe_init(KPipeRings<FM, FN>& r) {
 #pragma unroll
-  for (int i = 0; i < (FN == 5 ? 10 : 8); ++i) r.ra[i] = ig_u32x4{0u, 0u, 0u, 0u};
+  for (int i = 0; i < (FN == 5 ? 10 : 4); ++i) r.ra[i] = ig_u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < 4; ++i) r.rb[i] = ig_u32x4{0u, 0u, 0u, 0u};
 }
@@ -2029,23 +2051,30 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
   const int c_begin = sz * cps, c_end = min(nchunk_all, c_begin + cps);
   const int nchunk = c_end - c_begin, nk = nchunk * 9, kt0 = c_begin * 9;
 
+  // buffer-descriptor LDS-DMA (ig_lds_dma16): zero border / ragged rows through the descriptor's range check
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  const ig_u32x4 rs_w = ig_make_rsrc(Wt, (unsigned long long)p.Cout * p.ldw * 2);
+  const ig_u32x4 rs_x1 = ig_make_rsrc(X1, (unsigned long long)p.N * TH * TW * p.ldx * 2);
+  const ig_u32x4 rs_x2 = ig_make_rsrc(X2 ? X2 : X1, (unsigned long long)p.N * TH * TW * (X2 ? p.ldx2 : p.ldx) * 2);
+  const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring, hbuf_lds = (unsigned)(uintptr_t)(lptr_t)hbuf;
+  unsigned wvo[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) wvo[i] = woff[i] >= 0 ? (unsigned)woff[i] * 2u + wchunk * 16u : IG_OOB;
   auto issue_w = [&](int kt, int ring) {
-    unsigned char* st = wring + ring * WBYTES;
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-      const int qq = (wid + NW * i < WPIECES) ? wid + NW * i : wid;
-      const uint16_t* g = woff[i] >= 0 ? Wt + woff[i] + (kt0 + kt) * 64 + wchunk * 8 : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + qq * 1024), 16, 0, 0);
+      const int qq = (wid_s + NW * i < WPIECES) ? wid_s + NW * i : wid_s;
+      ig_lds_dma16(wring_lds + ring * WBYTES + qq * 1024, wvo[i], rs_w, (unsigned)(kt0 + kt) * 128u);
     }
   };
   auto issue_h = [&](int c, int t) {                                // c = chunk index local to this split
-    const int q = t * NW + wid;
-    int cc = (c_begin + c) * 64 + hchk[t] * 8;
-    const uint16_t* src = X1;
-    int ld = p.ldx;
-    if (cc >= p.C1) { src = X2; ld = p.ldx2; cc -= p.C1; }
-    const uint16_t* g = hpix[t] >= 0 ? src + hpix[t] * ld + cc : zero;
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(hbuf + (c & 1) * HBYTES + q * 1024), 16, 0, 0);
+    const int cb = (c_begin + c) * 64;                              // first channel of the chunk: decides the source (C1 % 64 == 0)
+    const bool second = cb >= p.C1;
+    const unsigned ld2 = (unsigned)(second ? p.ldx2 : p.ldx) * 2u;
+    const unsigned vo = hpix[t] >= 0 ? (unsigned)hpix[t] * ld2 + hchk[t] * 16u : IG_OOB;
+    const unsigned m0v = hbuf_lds + (c & 1) * HBYTES + (t * NW + wid_s) * 1024;
+    if (second) ig_lds_dma16(m0v, vo, rs_x2, (unsigned)(cb - p.C1) * 2u);
+    else ig_lds_dma16(m0v, vo, rs_x1, (unsigned)cb * 2u);
   };
   auto issue_ab = [&](int c) {                            // affine table of chunk c -> abuf[c & 1] (see igemm_halo_kernel)
     const float* t = p.gn_ab + ((long long)img0 * 2 + (lane >> 4 & 1)) * p.Cin + (c_begin + c) * 64 + (lane & 15) * 4;
