@@ -224,10 +224,11 @@ def write(out):
     txt += ktile("IG_ASM_KT_1x2", 1, 2, 6)
     txt += ktile("IG_ASM_KT_2x1", 2, 1, 6)
     txt += ktile("IG_ASM_KT_1x1", 1, 1, 6)
-    txt += ktile("IG_ASM_KT_2x4", 2, 4, 8)
+    txt += ktile("IG_ASM_KT_2x4", 2, 4, 6)
     txt += ktile("IG_ASM_KT_4x2", 4, 2, 8)
     txt += ktile("IG_ASM_KT_1x4", 1, 4, 8)
     txt += ktile("IG_ASM_KT_4x1", 4, 1, 8)
+    txt += ktile("IG_ASM_KT_1x10", 1, 10, 6)
     txt += ktile_pipe("IG_ASM_KP_1x5", 1, 5, 10, 4, 10)
     txt += ktile_pipe("IG_ASM_KP_2x2", 2, 2, 4, 4, 8)
     open(out, "w").write(txt)

@@ -24,6 +24,7 @@
 
 // 128 B of zeros: the global source of every padded / out-of-range 16-byte piece of the LDS-DMA loader.
 static __device__ uint4 g_zero_page[8];
+typedef uint32_t ig_u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -434,6 +435,76 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
   else staged_epilogue<FM, FN, WTM, WTN, BM, BN, NT, 1, false, F16>(p, acc, m0, n0, wm, wn, lane, gb, smem, owner, nimg_tile);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One 64-deep K tile of a wave's FM x FN fragment tile out of LDS, hand-scheduled (igemm_asm.inc, tools/gen_igemm_asm.py):
+// fragment reads run a register pool ahead of the MFMAs, every MFMA waits with a counted lgkmcnt for its own operands.
+// ab[b] = LDS byte address of activation fragment b at k-step 0 (row * 128 + ((lane half ^ swizzle) << 4)), aw = the same for the
+// wave's first weight fragment (fragment a: + a * 4096); rows are 128-byte, 128-aligned, slots XOR-swizzled with (row >> 1) & 7.
+#if UR_IGASM_ABL == 4
+#include "igemm_asm_abl4.inc"
+#elif UR_IGASM_ABL == 5
+#include "igemm_asm_abl5.inc"
+#else
+#include "igemm_asm.inc"
+#endif
+#ifndef UR_HALO_ABL
+#define UR_HALO_ABL 0      // timing-only ablations of igemm_halo_kernel (A/B builds): 1 = no DMA waits, 2 = no MFMA body
+#endif
+#define IG_MN(ASM, ...)                                                                      \
+  do {                                                                                       \
+    if constexpr (F16) asm volatile(ASM("v_mfma_f32_32x32x16_f16") __VA_ARGS__);             \
+    else asm volatile(ASM("v_mfma_f32_32x32x16_bf16") __VA_ARGS__);                          \
+  } while (0)
+template <int FM, int FN, bool F16>
+__device__ __forceinline__ void ktile_mma(f32x16 (&acc)[FN][FM], const unsigned (&ab)[FM], unsigned aw) {
+  ig_u32x4 t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
+  unsigned x0, x1, xw;
+#define KT_POOL6 "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5)
+#define KT_POOL8 KT_POOL6, "=&v"(t6), "=&v"(t7)
+#define KT_POOL10 KT_POOL8, "=&v"(t8), "=&v"(t9)
+  if constexpr (FM == 1 && FN == 5) {
+    IG_MN(IG_ASM_KT_1x5, : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[4][0]), KT_POOL10, "=&v"(x0), "=&v"(xw)
+          : "v"(ab[0]), "v"(aw) : "memory");
+  } else if constexpr (FM == 2 && FN == 2) {
+    IG_MN(IG_ASM_KT_2x2, : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), KT_POOL8, "=&v"(x0), "=&v"(x1), "=&v"(xw)
+          : "v"(ab[0]), "v"(ab[1]), "v"(aw) : "memory");
+  } else if constexpr (FM == 1 && FN == 1) {
+    IG_MN(IG_ASM_KT_1x1, : "+v"(acc[0][0]), KT_POOL6, "=&v"(x0), "=&v"(xw) : "v"(ab[0]), "v"(aw) : "memory");
+  } else if constexpr (FM == 2 && FN == 1) {
+    IG_MN(IG_ASM_KT_2x1, : "+v"(acc[0][0]), "+v"(acc[0][1]), KT_POOL6, "=&v"(x0), "=&v"(x1), "=&v"(xw) : "v"(ab[0]), "v"(ab[1]), "v"(aw) : "memory");
+  } else if constexpr (FM == 2 && FN == 4) {
+    // (128 / 160 accumulator registers at two waves per SIMD: "a" lets them live in the AGPR half of the 256-register budget)
+    IG_MN(IG_ASM_KT_2x4, : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]),
+          KT_POOL6, "=&v"(x0), "=&v"(x1), "=&v"(xw) : "v"(ab[0]), "v"(ab[1]), "v"(aw) : "memory");
+  } else if constexpr (FM == 1 && FN == 10) {
+    IG_MN(IG_ASM_KT_1x10, : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[4][0]), "+v"(acc[5][0]), "+v"(acc[6][0]), "+v"(acc[7][0]),
+          "+v"(acc[8][0]), "+v"(acc[9][0]), KT_POOL6, "=&v"(x0), "=&v"(xw) : "v"(ab[0]), "v"(aw) : "memory");
+  } else {
+    static_assert(FM == 0, "no hand-scheduled K tile for this fragment shape");
+  }
+#undef KT_POOL6
+#undef KT_POOL8
+#undef KT_POOL10
+}
+// (GEMM kernels) shapes with a generated K-tile body
+template <int FM, int FN> constexpr bool ktile_gemm_ok() {
+#if defined(UR_IGEMM_NOASM) || defined(UR_GEMM_NOASM)
+  return false;
+#else
+  // (not the 1 x 10 / 2 x 4 tiles of the 256-wide kernels: 160 / 128 accumulator registers at two waves per SIMD leave no room for
+  // the fragment pool - "+v" spilled 96-332 B and "+a" did not allocate at all; hipcc's own schedule stays there)
+  return (FM == 1 && (FN == 1 || FN == 5 || FN == 10)) || (FM == 2 && (FN == 1 || FN == 2 || FN == 4));
+#endif
+}
+template <int FM, int FN> constexpr bool ktile_asm_ok() {
+#ifdef UR_IGEMM_NOASM
+  return false;
+#else
+  return (FM == 1 && FN == 5) || (FM == 2 && FN == 2);
+#endif
+}
+
+
 template <int BM, int BN, int WM, int WN, bool G1, bool F16>
 __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
   // G1: pure GEMM (1x1, stride 1, one source, no padding): rows are plain offsets, no im2col state, no tap bookkeeping
@@ -564,7 +635,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   const int frow = lane & 31, fhalf = lane >> 5;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // LDS byte addresses (stage 0, k-step 0) of the wave's first activation / weight fragment for the hand-scheduled K tile
+  const unsigned kt_x0 = (unsigned)(uintptr_t)(lptr_t)smem + (wm * WTM + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  const unsigned kt_w0 = (unsigned)(uintptr_t)(lptr_t)smem + (BM + wn * WTN + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  static_assert(WTM % 32 == 0 && ((WTN >> 1) & 7) == 0, "fragment rows must keep the swizzle phase of row 0");
   auto compute = [&](int stage) {
+    if constexpr (ktile_gemm_ok<FM, FN>()) {
+      unsigned ab[FM];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) ab[b] = kt_x0 + stage * STAGE + b * 4096;
+      ktile_mma<FM, FN, F16>(acc, ab, kt_w0 + stage * STAGE);
+      return;
+    }
     const unsigned char* xs = smem + stage * STAGE;
     const unsigned char* wsm = xs + BM * 128;
 #pragma unroll
@@ -605,6 +688,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     }
   }
 
+  if constexpr (ktile_gemm_ok<FM, FN>()) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // last asm MFMA -> VALU reads of the accumulators
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, 256, F16>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
 }
 
@@ -973,7 +1057,18 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   const int frow = lane & 31, fhalf = lane >> 5;
+  // LDS byte addresses (stage 0, k-step 0) of the wave's first activation / weight fragment for the hand-scheduled K tile
+  const unsigned kt_x0 = (unsigned)(uintptr_t)(lptr_t)smem + (wm * WTM + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  const unsigned kt_w0 = (unsigned)(uintptr_t)(lptr_t)smem + (BM + wn * WTN + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  static_assert(WTM % 32 == 0 && ((WTN >> 1) & 7) == 0, "fragment rows must keep the swizzle phase of row 0");
   auto compute = [&](int stage) {
+    if constexpr (ktile_gemm_ok<FM, FN>()) {
+      unsigned ab[FM];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) ab[b] = kt_x0 + stage * STAGE + b * 4096;
+      ktile_mma<FM, FN, F16>(acc, ab, kt_w0 + stage * STAGE);
+      return;
+    }
     const unsigned char* xs = smem + stage * STAGE;
     const unsigned char* wsm = xs + BM * 128;
 #pragma unroll
@@ -1017,7 +1112,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
     for (int t = 0; t < ntile; ++t) {
       const bool more = issued < ntile;
       if (more) { if (!(p.dbg & 1)) issue_tile(is); ++issued; is = (is + 1 == NST) ? 0 : is + 1; }
-      if (!(p.dbg & 2)) compute(cs);
+      compute(cs);                                        // (no run-time condition around the asm K tile: hipcc spills its operands then)
       cs = (cs + 1 == NST) ? 0 : cs + 1;
       // tile t+1 must have landed before anyone reads it: all but the newest (NST-2) tiles' DMAs retired
       if (issued - (t + 1) >= NST - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD * (NST - 2)) : "memory");
@@ -1026,10 +1121,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
     }
   }
   if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.y)[0] = 1.f; return; }
+  if constexpr (ktile_gemm_ok<FM, FN>()) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // last asm MFMA -> VALU reads of the accumulators
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16>(p, acc, m0, n0, wm, wn, lane, gb, sz, smem);
 }
 
-typedef uint32_t ig_u32x4 __attribute__((ext_vector_type(4)));
 // LDS-DMA of one 1-KiB piece (64 lanes x 16 bytes -> LDS bytes [m0v, m0v + 1024)) through a raw buffer descriptor: lane address =
 // base + voff + soff, and a lane whose voff is past num_records reads ZERO - the convolution's zero padding, ragged Cout rows and
 // the K tail cost no select, no zero page and no 64-bit address arithmetic (the global_load_lds form needed ~10 VALU + a
@@ -1133,6 +1228,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
   const int frow = lane & 31, fhalf = lane >> 5;
+  // LDS byte addresses (stage 0, k-step 0) of the wave's first activation / weight fragment for the hand-scheduled K tile
+  const unsigned kt_x0 = (unsigned)(uintptr_t)(lptr_t)smem + (wm * WTM + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  const unsigned kt_w0 = (unsigned)(uintptr_t)(lptr_t)smem + (BM + wn * WTN + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  static_assert(WTM % 32 == 0 && ((WTN >> 1) & 7) == 0, "fragment rows must keep the swizzle phase of row 0");
   const int ntile = (p.dbg & 8) ? 0 : p.nk;               // (dbg bits: timing-only ablations, UR_IGEMM_DBG)
   int issued = 0;
 #pragma unroll
@@ -1146,6 +1245,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
     if (issued < ntile) { issue_tile(is); ++issued; is = (is + 1 == NST) ? 0 : is + 1; }
     const unsigned char* xs = smem + cs * STAGE;
     const unsigned char* wsm = xs + BM * 128;
+    if constexpr (ktile_gemm_ok<FM, FN>()) {                // (no run-time condition around the asm block: hipcc spills its operands then)
+      unsigned ab[FM];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) ab[b] = kt_x0 + cs * STAGE + b * 4096;
+      ktile_mma<FM, FN, F16>(acc, ab, kt_w0 + cs * STAGE);
+    } else
     if (!(p.dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -1173,6 +1278,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
     __builtin_amdgcn_s_barrier();
   }
   if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.y)[0] = 1.f; return; }
+  if constexpr (ktile_gemm_ok<FM, FN>()) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // last asm MFMA -> VALU reads of the accumulators
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, DIRECT, PAIRC>(p, acc, m0, n0, wm, wn, lane, gb, 0, smem);
 }
 
@@ -1249,50 +1355,6 @@ __device__ __forceinline__ void gn_piece_inplace(unsigned char* piece, const GnA
     for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
   }
   *reinterpret_cast<uint4*>(piece) = pack8t<F16>(f);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// One 64-deep K tile of a wave's FM x FN fragment tile out of LDS, hand-scheduled (igemm_asm.inc, tools/gen_igemm_asm.py):
-// fragment reads run a register pool ahead of the MFMAs, every MFMA waits with a counted lgkmcnt for its own operands.
-// ab[b] = LDS byte address of activation fragment b at k-step 0 (row * 128 + ((lane half ^ swizzle) << 4)), aw = the same for the
-// wave's first weight fragment (fragment a: + a * 4096); rows are 128-byte, 128-aligned, slots XOR-swizzled with (row >> 1) & 7.
-#if UR_IGASM_ABL == 4
-#include "igemm_asm_abl4.inc"
-#elif UR_IGASM_ABL == 5
-#include "igemm_asm_abl5.inc"
-#else
-#include "igemm_asm.inc"
-#endif
-#ifndef UR_HALO_ABL
-#define UR_HALO_ABL 0      // timing-only ablations of igemm_halo_kernel (A/B builds): 1 = no DMA waits, 2 = no MFMA body
-#endif
-#define IG_MN(ASM, ...)                                                                      \
-  do {                                                                                       \
-    if constexpr (F16) asm volatile(ASM("v_mfma_f32_32x32x16_f16") __VA_ARGS__);             \
-    else asm volatile(ASM("v_mfma_f32_32x32x16_bf16") __VA_ARGS__);                          \
-  } while (0)
-template <int FM, int FN, bool F16>
-__device__ __forceinline__ void ktile_mma(f32x16 (&acc)[FN][FM], const unsigned (&ab)[FM], unsigned aw) {
-  ig_u32x4 t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
-  unsigned x0, x1, xw;
-  if constexpr (FM == 1 && FN == 5) {
-    IG_MN(IG_ASM_KT_1x5, : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[4][0]),
-          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(t8), "=&v"(t9), "=&v"(x0), "=&v"(xw)
-          : "v"(ab[0]), "v"(aw) : "memory");
-  } else if constexpr (FM == 2 && FN == 2) {
-    IG_MN(IG_ASM_KT_2x2, : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),
-          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(x0), "=&v"(x1), "=&v"(xw)
-          : "v"(ab[0]), "v"(ab[1]), "v"(aw) : "memory");
-  } else {
-    static_assert(FM == 0, "no hand-scheduled K tile for this fragment shape");
-  }
-}
-template <int FM, int FN> constexpr bool ktile_asm_ok() {
-#ifdef UR_IGEMM_NOASM
-  return false;
-#else
-  return (FM == 1 && FN == 5) || (FM == 2 && FN == 2);
-#endif
 }
 
 // Tap-crossing software pipeline of the halo convs (igemm_asm.inc, ktile_pipe in tools/gen_igemm_asm.py): the K tile's MFMAs are two
