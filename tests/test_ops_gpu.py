@@ -440,3 +440,51 @@ def test_conv_groupnorm_prologue(ops, n, c1, c2, cout, h, w, ups):
     if not ops.conv_plan(_nhwc(x[:, :8, :5, :7]), ops.pack_conv(wt[:, :8], b, "cuda"), gn_ab=True).prologue_ok:
         with pytest.raises(NotImplementedError):                      # UR_E_UNSUPPORTED where the launch cannot honour gn_ab
             ops.conv(_nhwc(x[:, :8, :5, :7]), ops.pack_conv(wt[:, :8], b, "cuda"), gn_ab=ab, gn_silu=True)
+
+
+@pytest.mark.parametrize("m,k,n", [(4100, 200, 264), (8192, 72, 640), (1000, 328, 1288)])
+def test_linear_k_tail_and_ragged_tiles(ops, m, k, n):
+    """1x1 / Linear shapes whose K is not a multiple of the 64-deep K tile and whose M / N do not fill the last tiles: the buffer-
+    descriptor loaders return zeros for rows past M / Cout (range check) and for the K tail (per-lane select)."""
+    g = _gen(m + k + n)
+    x = _rb(torch.randn(m, k, generator=g)); w = _rb(torch.randn(n, k, generator=g) / math.sqrt(k)); b = torch.randn(n, generator=g)
+    r = _rb(torch.randn(m, n, generator=g))
+    y = ops.linear(x.to(DT).cuda(), ops.pack_conv(w, b, "cuda"), residual=r.to(DT).cuda())
+    assert rel_l2(y.float().cpu(), F.linear(x, w, b) + r) < TOL_BF16
+
+
+_HALO_AB_SNIPPET = r"""
+import sys, math, torch
+sys.path.insert(0, {root!r})
+from unirestore_amd import ops
+ops.set_dtype({dt!r})
+DT = ops.act_dtype()
+outs = []
+for (n, cin, cout, h, w, ups) in {cases!r}:
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g).to(DT); wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(DT).float()
+    b = torch.randn(cout, generator=g)
+    y = ops.conv(x.permute(0, 2, 3, 1).contiguous().cuda(), ops.pack_conv(wt, b, "cuda"), upsample=ups, gn=True)
+    outs.append(y.cpu()); outs.append(ops.gn_of(y)[0].cpu())
+torch.save(outs, {out!r})
+"""
+
+
+def test_conv_halo_wave_specialised_equals_self_loading_kernel(ops, tmp_path):
+    """The wave-specialised halo conv (8 compute waves + 1 loader wave, tap-crossing fragment pipeline, buffer-descriptor DMA) and the
+    kernel whose waves load for themselves (UR_HALO_NOWS=1, read once per process: second process) accumulate in the same order:
+    outputs and GroupNorm partial planes must be BIT-identical, on full tiles, ragged Cout tiles, the fused upsample and both widths."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(2, 128, 320, 16, 64, False), (1, 192, 200, 8, 32, False), (2, 64, 256, 8, 16, True), (1, 320, 160, 24, 32, False)]
+    dt = "fp16" if DT == torch.float16 else "bf16"
+    res = []
+    for tag, env in (("ws", {}), ("nows", {"UR_HALO_NOWS": "1"})):
+        out = str(tmp_path / f"{tag}.pt")
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _HALO_AB_SNIPPET.format(root=root, dt=dt, cases=cases, out=out)], env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(torch.load(out))
+    assert len(res[0]) == len(res[1]) == 2 * len(cases)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
