@@ -1,16 +1,13 @@
 #!/bin/bash
 cd /root/repo
 export TMPDIR=/tmp
-UR_HALO_2X5=1 timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -k "conv" 2>&1 | tail -2
-ONLY="unet c3" timeout 300 python tools/bench_shapes.py 2>&1 | grep -v amdgpu.ids | grep "@64"
-ONLY="unet c3" UR_HALO_2X5=1 timeout 300 python tools/bench_shapes.py 2>&1 | grep -v amdgpu.ids | grep "@64"
-for v in w8 w4 w8 w4; do
-  if [ $v = w4 ]; then export UR_HALO_2X5=1; else unset UR_HALO_2X5; fi
-  timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp16 > gpurun_out/bench_ab_$v.json 2>/dev/null
-  python - <<PY
+timeout 2700 python -m pytest tests -q -m gpu 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py > gpurun_out/bench_r3_d.json 2> gpurun_out/bench_r3_d.err; python - <<'PY'
 import json
-d=json.loads([l for l in open('gpurun_out/bench_ab_$v.json') if l.startswith('{')][-1])
-f=d['families']
-print('$v', round(d['ms_per_step'],1), 'gemm', f['gemm1x1_igemm']['ms'], 'conv', f['conv3x3_igemm']['ms'], 'attn', f['attention']['ms'])
+d=json.loads([l for l in open('gpurun_out/bench_r3_d.json') if l.startswith('{')][-1])
+print({k:d[k] for k in ('value','ms_per_step','fp16','steps','warmup')})
+print(d['roofline'])
+for k,v in sorted(d['families'].items(), key=lambda kv:-kv[1]['ms'])[:9]: print(k, v['launches'], v['ms'], v.get('tflops'))
+print(d['cpu_baseline']); print(d['parity_vs_oracle']['bf16'], d['parity_vs_oracle']['fp16'])
 PY
-done
