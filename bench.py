@@ -248,6 +248,9 @@ def main():
                     result["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
                     result["roofline"]["traffic_algorithmic"] = pj["algorithmic_bytes_per_launch"]
                     result["roofline"]["traffic_note"] = pj["note"]
+                    if "k_loop_shader_clock_ghz" in pj:      # in-kernel s_memtime / s_memrealtime of the dominant launch
+                        result["roofline"]["sustained_clock_ghz"] = pj["k_loop_shader_clock_ghz"]
+                        result["roofline"]["peak_at_sustained_clock"] = round(2500.0 * pj["k_loop_shader_clock_ghz"] / 2.4, 1)
                     break
         result["families"] = fam
         result["profiled_forward_ms"] = round(sum(v["ms"] for v in rep.values()), 2)

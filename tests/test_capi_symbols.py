@@ -90,3 +90,34 @@ def test_ctypes_struct_layout_matches_the_header(tmp_path):
     for n in fields:
         assert int(out[n]) == getattr(capi.ConvDesc, n).offset, n
     assert int(out["sizeof"]) == ctypes.sizeof(capi.ConvDesc) and int(out["plan"]) == ctypes.sizeof(capi.ConvPlan)
+
+
+def test_generated_asm_blocks_are_current(tmp_path):
+    """csrc/tchain_asm*.inc and csrc/igemm_asm*.inc are GENERATED (tools/gen_chain_asm.py, tools/gen_igemm_asm.py): the committed
+    files must be exactly what the generators emit."""
+    import importlib.util
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools = tmp_path / "tools"
+    out = tmp_path / "unirestore_amd" / "csrc"
+    tools.mkdir(parents=True); out.mkdir(parents=True)
+    for f in ("gen_chain_asm.py", "gen_igemm_asm.py"):
+        shutil.copy(os.path.join(root, "tools", f), tools / f)
+    import sys
+    sys.path.insert(0, str(tools))
+    try:
+        for mod in ("gen_chain_asm", "gen_igemm_asm"):
+            sys.modules.pop(mod, None)
+            spec = importlib.util.spec_from_file_location(mod, str(tools / (mod + ".py")))
+            m = importlib.util.module_from_spec(spec)
+            sys.modules[mod] = m
+            spec.loader.exec_module(m)
+            m.main()
+    finally:
+        sys.path.remove(str(tools))
+        for mod in ("gen_chain_asm", "gen_igemm_asm"):
+            sys.modules.pop(mod, None)
+    made = sorted(os.listdir(out))
+    assert made == ["igemm_asm.inc", "igemm_asm_abl4.inc", "igemm_asm_abl5.inc", "tchain_asm.inc", "tchain_asm_abl4.inc", "tchain_asm_abl5.inc"]
+    for f in made:
+        assert (out / f).read_text() == open(os.path.join(root, "unirestore_amd", "csrc", f)).read(), f
