@@ -110,14 +110,14 @@ __global__ void gn_finalize_kernel(const float* __restrict__ p1, int P1, int C1,
 // C = channels of THIS source tensor; it occupies channels [c_off, c_off+C) of the C_total-wide (virtually
 // concatenated) normalisation domain; y has row stride C_total.
 template <bool F16>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
-                                                       const float* __restrict__ ab, int HW, int C, int silu,
-                                                       int pix_per_block, int c_off, int C_total, int CVS) {
+__device__ __forceinline__ void gn_apply_body(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                              const float* __restrict__ ab, int HW, int C, int silu,
+                                              int pix_per_block, int c_off, int C_total, int CVS, int bx, int bz) {
   const int n = blockIdx.y, t = threadIdx.x;
   const int CV = C >> 3, R = 256 / CVS;
-  const int r = t / CVS, v = blockIdx.z * CVS + (t - r * CVS);
+  const int r = t / CVS, v = bz * CVS + (t - r * CVS);
   if (r >= R || v >= CV) return;
-  const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+  const int p_begin = bx * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
   const uint16_t* xi = x + (long long)n * HW * C + v * 8;
   uint4 raw[4];
   if (p_begin + r < p_end) {            // first batch of loads issued ahead of the coefficient loads
@@ -150,6 +150,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
       }
       *reinterpret_cast<uint4*>(yo + (long long)pp * C_total) = pack8t<F16>(f);
     }
+  }
+}
+template <bool F16>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                       const float* __restrict__ ab, int HW, int C, int silu,
+                                                       int pix_per_block, int c_off, int C_total, int CVS) {
+  gn_apply_body<F16>(x, y, ab, HW, C, silu, pix_per_block, c_off, C_total, CVS, blockIdx.x, blockIdx.z);
+}
+// both sources of a virtually concatenated input in ONE launch: blockIdx.z < slabs1 -> source 1, else source 2 (own geometry)
+template <bool F16>
+__global__ __launch_bounds__(256) void gn_apply2_kernel(const uint16_t* __restrict__ x1, const uint16_t* __restrict__ x2, uint16_t* __restrict__ y,
+                                                        const float* __restrict__ ab, int HW, int C1, int C2, int silu, int ppb1, int ppb2,
+                                                        int cvs1, int cvs2, int slabs1, int chunks1, int chunks2) {
+  if ((int)blockIdx.z < slabs1) {
+    if ((int)blockIdx.x < chunks1) gn_apply_body<F16>(x1, y, ab, HW, C1, silu, ppb1, 0, C1 + C2, cvs1, blockIdx.x, blockIdx.z);
+  } else if ((int)blockIdx.x < chunks2) {
+    gn_apply_body<F16>(x2, y, ab, HW, C2, silu, ppb2, C1, C1 + C2, cvs2, blockIdx.x, blockIdx.z - slabs1);
   }
 }
 
@@ -322,6 +339,15 @@ int ur_groupnorm_apply_act(const void* x, const void* x2, void* y, const float* 
   const uint16_t* src[2] = {(const uint16_t*)x, (const uint16_t*)x2};
   const int cs[2] = {C1, x2 ? C2 : 0}, off[2] = {0, C1};
   static const int ppt = getenv("UR_GN_PPT") ? atoi(getenv("UR_GN_PPT")) : 8;
+  static const bool one_launch = getenv("UR_GN_TWO_LAUNCHES") == nullptr;
+  if (one_launch && cs[1] > 0) {                          // virtual concat: one launch for both sources
+    int cvs1, slabs1, chunks1, ppb1, cvs2, slabs2, chunks2, ppb2;
+    gn_geom(N, HW, cs[0], ppt, cvs1, slabs1, chunks1, ppb1);
+    gn_geom(N, HW, cs[1], ppt, cvs2, slabs2, chunks2, ppb2);
+    UR_DT_SWITCH(dtype, hipLaunchKernelGGL(gn_apply2_kernel<F16>, dim3(std::max(chunks1, chunks2), N, slabs1 + slabs2), dim3(256), 0, s, src[0], src[1],
+                                           (uint16_t*)y, ab, HW, cs[0], cs[1], silu, ppb1, ppb2, cvs1, cvs2, slabs1, chunks1, chunks2));
+    return ur::check_launch("ur_groupnorm_apply_act");
+  }
   for (int i = 0; i < 2; ++i) {
     if (cs[i] <= 0) continue;
     int cvs, slabs, chunks, ppb;
