@@ -41,10 +41,18 @@ def test_no_kernel_uses_scratch_memory():
     usage = json.load(open(path))
     assert len(usage) >= 40
     # The token-stationary chain kernels (csrc/tchain.hip) run ONE wave per SIMD on the whole 512-entry register file by design;
-    # hipcc parks a handful of lane-constant scalars of the HEAD / TAIL kinds (lane id, address offsets: <= 32 dwords, stored once
-    # at kernel entry, reloaded between phases, never inside the FF loop) in scratch.  Anything beyond that - or any other kernel
-    # touching scratch at all - fails.
-    allowed = lambda k: 128 if ("tchain_head_kernel" in k or "tchain_tail_kernel" in k) else 0
+    # hipcc parks a handful of lane-constant scalars of the HEAD / TAIL kinds (lane id, address offsets, stored once at kernel
+    # entry, reloaded between phases, never inside the FF loop) in scratch.  The allowance is PINNED to the measured bytes per
+    # kernel and 16-bit type (hipcc 7.2): a compiler or source change that spills more - or any other kernel touching scratch at
+    # all - fails here and has to be looked at (and, if it is the same kind of spill, re-pinned deliberately).
+    pinned = {("tchain_head_kernel", "Lb0E"): 20, ("tchain_head_kernel", "Lb1E"): 0,
+              ("tchain_tail_kernel", "Lb0E"): 52, ("tchain_tail_kernel", "Lb1E"): 68}
+
+    def allowed(k):
+        for (name, dt), v in pinned.items():
+            if name in k and f"{name}I{dt}" in k:
+                return v
+        return 0
     bad = {k: v["ScratchSize"] for k, v in usage.items() if v.get("ScratchSize", 0) > allowed(k)}
     assert not bad, bad
     assert all(v.get("ScratchSize", 0) == 0 for k, v in usage.items() if "tchain_mlp_kernel" in k)
@@ -93,14 +101,14 @@ def test_ctypes_struct_layout_matches_the_header(tmp_path):
 
 
 def test_generated_asm_blocks_are_current(tmp_path):
-    """csrc/tchain_asm*.inc and csrc/igemm_asm*.inc are GENERATED (tools/gen_chain_asm.py, tools/gen_igemm_asm.py): the committed
-    files must be exactly what the generators emit."""
+    """csrc/tchain_asm.inc, csrc/igemm_asm.inc and their timing-only variants tools/ab/*_abl{4,5}.inc are GENERATED
+    (tools/gen_chain_asm.py, tools/gen_igemm_asm.py): the committed files must be exactly what the generators emit."""
     import importlib.util
     import shutil
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tools = tmp_path / "tools"
     out = tmp_path / "unirestore_amd" / "csrc"
-    tools.mkdir(parents=True); out.mkdir(parents=True)
+    tools.mkdir(parents=True); out.mkdir(parents=True); (tools / "ab").mkdir()
     for f in ("gen_chain_asm.py", "gen_igemm_asm.py"):
         shutil.copy(os.path.join(root, "tools", f), tools / f)
     import sys
@@ -118,6 +126,10 @@ def test_generated_asm_blocks_are_current(tmp_path):
         for mod in ("gen_chain_asm", "gen_igemm_asm"):
             sys.modules.pop(mod, None)
     made = sorted(os.listdir(out))
-    assert made == ["igemm_asm.inc", "igemm_asm_abl4.inc", "igemm_asm_abl5.inc", "tchain_asm.inc", "tchain_asm_abl4.inc", "tchain_asm_abl5.inc"]
+    assert made == ["igemm_asm.inc", "tchain_asm.inc"]
     for f in made:
         assert (out / f).read_text() == open(os.path.join(root, "unirestore_amd", "csrc", f)).read(), f
+    made_ab = sorted(os.listdir(tools / "ab"))
+    assert made_ab == ["igemm_asm_abl4.inc", "igemm_asm_abl5.inc", "tchain_asm_abl4.inc", "tchain_asm_abl5.inc"]
+    for f in made_ab:
+        assert (tools / "ab" / f).read_text() == open(os.path.join(root, "tools", "ab", f)).read(), f

@@ -64,7 +64,24 @@ def test_tfa_golden(M, gdt, name):
         assert c is None
 
 
-@pytest.mark.parametrize("name", ["cfrm_1"])
+def test_csce_golden_production_shape_runs_the_chain_kernel(M, gdt):
+    """csce_3 = the reference's CSCEAdapter(320,320,256) at 256 tokens per image: the shape production runs 80x per forward.  The
+    reference-generated vector must go through tchain_csce_kernel (ONE launch of the chain family, no per-layer GEMM)."""
+    from unirestore_amd import ops
+    w, i, o = load_golden("csce_3")
+    m = M.CSCEAdapter(320, 320, 256)
+    m.load_state_dict(w)
+    m(i["x"], i["condition"])                     # packs the weight stream
+    ops.profile_enable(True)
+    y = m(i["x"], i["condition"])
+    torch.cuda.synchronize()
+    rep = ops.profile_report()
+    ops.profile_enable(False)
+    assert rep.get("chain_csce", {}).get("launches") == 1 and "gemm1x1_igemm" not in rep, rep
+    assert rel_l2(y.cpu(), o["y"]) < GTOL[gdt]
+
+
+@pytest.mark.parametrize("name", ["cfrm_1", "cfrm_2"])
 def test_cfrm_golden(M, gdt, name):
     w, i, o = load_golden(name)
     c = w["0.conv1.weight"].shape[1]

@@ -1,4 +1,4 @@
-"""Bit-determinism probe at full size: python tools/det_check.py [steps] [batch] [dtype]  (env UR_CSCE_STREAM=0/1)"""
+"""Bit-determinism probe at full size: python tools/det_check.py [steps] [batch] [dtype]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch, bench
@@ -10,7 +10,7 @@ img = torch.rand(b, 3, 512, 512, generator=g, device=dev)
 nz = (torch.randn(b, 4, 64, 64, generator=g, device=dev), torch.randn(b, 4, 64, 64, generator=g, device=dev))
 outs = [m(img, "ir", noise=nz, return_latents=True) for _ in range(4)]
 for i in range(1, 4):
-    print(f"steps={steps} B={b} {dt} stream={os.environ.get('UR_CSCE_STREAM','0')} replay0 vs replay{i}:",
+    print(f"steps={steps} B={b} {dt} replay0 vs replay{i}:",
           [bool(torch.equal(x, y)) for x, y in zip(outs[0], outs[i])], [float((x - y).abs().max()) for x, y in zip(outs[0], outs[i])])
 m.use_graph = False
 e = [m(img, "ir", noise=nz, return_latents=True) for _ in range(2)]

@@ -1,6 +1,5 @@
 """Find the first op whose output differs between two eager runs (full size): python tools/det_trace.py [steps] [batch] [dtype]"""
 import os, sys
-os.environ.setdefault("UR_CSCE_STREAM", "0")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch, bench
 from unirestore_amd import ops

@@ -145,7 +145,7 @@ def main():
     global ABL
     here = os.path.dirname(os.path.abspath(__file__))
     for ABL in (4, 5, 0):
-        write(os.path.join(here, "..", "unirestore_amd", "csrc", f"tchain_asm_abl{ABL}.inc" if ABL else "tchain_asm.inc"))
+        write(os.path.join(here, "ab", f"tchain_asm_abl{ABL}.inc") if ABL else os.path.join(here, "..", "unirestore_amd", "csrc", "tchain_asm.inc"))
 
 
 def write(out):

@@ -106,6 +106,32 @@ def main():
     x, cond = torch.randn(2, 320, 8, 8, generator=g2), torch.randn(2, 256, 8, 8, generator=g2)
     _save("csce_2", m, dict(x=x, condition=cond), dict(y=m(x, cond)))
 
+    # Round 4: shapes that reach the kernels PRODUCTION runs, each from its own generator.
+    #  csce_3: CSCEAdapter(320,320,256) at 16x16 = 256 tokens per image -> the token-stationary tchain_csce_kernel (scedit.py:24-38)
+    #  csce_4: CSCEAdapter(640,640,256) at 8x16 -> the 640-wide per-layer path with the schedule-batched proj(cond)
+    #  cfrm_2: Sequential(NAFBlock(128), AdaNAFV2(128)) at 16x16 -> the 128/256/512-wide CFRM tiles (cfrm.py:12-54, nafnet_arch.py:28-131)
+    #  tfa_4 : TaskFeatureAdapter(512,128,1,last_layer=True) at 16x16, 1.26 M parameters (taskeditor.py:10-108)
+    g3 = torch.Generator().manual_seed(20250916)
+    torch.manual_seed(103)
+    m = scedit.CSCEAdapter(320, 320, 256).eval()
+    x, cond = torch.randn(2, 320, 16, 16, generator=g3), torch.randn(2, 256, 16, 16, generator=g3)
+    _save("csce_3", m, dict(x=x, condition=cond), dict(y=m(x, cond)))
+    torch.manual_seed(104)
+    m = scedit.CSCEAdapter(640, 640, 256).eval()
+    x, cond = torch.randn(2, 640, 8, 16, generator=g3), torch.randn(2, 256, 8, 16, generator=g3)
+    _save("csce_4", m, dict(x=x, condition=cond), dict(y=m(x, cond)))
+    torch.manual_seed(302)
+    m = nn.Sequential(naf.NAFBlock(128), cfrm.AdaNAFV2(128)).eval()
+    _randomise(m, g3)
+    x = torch.randn(2, 128, 16, 16, generator=g3)
+    _save("cfrm_2", m, dict(x=x), dict(y=m(x)))
+    torch.manual_seed(204)
+    m = taskeditor.TaskFeatureAdapter(512, 128, 1, True).eval()
+    x, skip, cond = torch.randn(2, 512, 16, 16, generator=g3), torch.randn(2, 128, 16, 16, generator=g3), torch.randn(2, 1, 128, generator=g3)
+    y, nc = m(x, skip, cond)
+    assert sum(p.numel() for p in m.parameters()) == 1263232       # SURVEY 8(c) KAT
+    _save("tfa_4", m, dict(x=x, skip=skip, condition=cond), dict(x=y, condition=nc))
+
 
 if __name__ == "__main__":
     main()

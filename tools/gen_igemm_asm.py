@@ -214,7 +214,8 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     for abl in (4, 5, 0):             # timing-only variants (4 = no fragment reads, 5 = no MFMAs) for A/B builds, then the real file
         gen_chain_asm.ABL = abl
-        write(os.path.join(here, "..", "unirestore_amd", "csrc", f"igemm_asm_abl{abl}.inc" if abl else "igemm_asm.inc"))
+        # the shipped file lives in csrc/; the timing-only variants next to the A/B tooling (tools/ab/, selected by -DUR_IGASM_ABL=4|5)
+        write(os.path.join(here, "ab", f"igemm_asm_abl{abl}.inc") if abl else os.path.join(here, "..", "unirestore_amd", "csrc", "igemm_asm.inc"))
 
 
 def write(out):

@@ -53,9 +53,10 @@ def resolve(cfg: dict, allow_16bit: bool = False) -> dict:
         raise ValueError(f"trainer.accelerator={tr.get('accelerator')!r}: the MI355X path has no CPU fallback (use accelerator: gpu)")
     prec = str(tr.get("precision", "bf16-mixed"))
     if prec in PRECISIONS_32:
+        allow_16bit = allow_16bit or os.environ.get("UR_ALLOW_16BIT", "0") == "1"      # opt-in without editing the command line
         if not allow_16bit:
             raise ValueError(f"trainer.precision={prec!r}: this path computes with 16-bit MFMA operands (fp32 accumulation); pass "
-                             "--allow-16bit (allow_16bit=True) to run the config in fp16, or set precision to bf16-mixed / 16-mixed")
+                             "--allow-16bit (allow_16bit=True, or UR_ALLOW_16BIT=1 in the environment) to run the config in fp16, or set precision to bf16-mixed / 16-mixed")
         import warnings
         warnings.warn(f"trainer.precision={prec!r} runs as fp16 storage + fp32 accumulation (no fp32 matrix path on this backend)")
         dtype = "fp16"

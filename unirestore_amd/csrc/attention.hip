@@ -269,10 +269,9 @@ int UR_ATTN_LAUNCH(const void* pp, int D, hipStream_t s) {
     hipLaunchKernelGGL((attn_fwd_kernel<64, F16>), grid, block, lds, s, p);
   } else {
     constexpr int lds = 2 * (64 * 256 + 128 * 128);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ur::DeviceOnce attr_once;    // the attribute is per device
+    if (attr_once.first()) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<128, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
     }
     hipLaunchKernelGGL((attn_fwd_kernel<128, F16>), grid, block, lds, s, p);
   }

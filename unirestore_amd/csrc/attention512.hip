@@ -222,10 +222,9 @@ __global__ __launch_bounds__(256, 1) void attn512_kernel(const AttnP p) {
 int UR_ATTN512_LAUNCH(const void* pp, hipStream_t s) {
   const AttnP& p = *static_cast<const AttnP*>(pp);
   constexpr bool F16 = UR_TU_F16 != 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&attn512_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, A5_LDS);
-    attr_set = true;
   }
   dim3 grid((p.Tq + A5_BQ - 1) / A5_BQ, p.B * p.H), block(256);
   hipLaunchKernelGGL((attn512_kernel<F16>), grid, block, A5_LDS, s, p);

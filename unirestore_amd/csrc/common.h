@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/unirestore_hip.h"
@@ -137,6 +138,18 @@ void zero_async(void* ptr, size_t bytes, hipStream_t s);
 // per-(image, channel) sum / sum-of-squares of a dense NHWC bf16 tensor, accumulated into fp64 stats[N][C][2] (norms.hip)
 int gn_stats_parts(int N, int HW, int C);
 int gn_stats_launch(const void* x, float* part, int N, int HW, int C, int dtype, hipStream_t s);
+
+// `first()` is true once per DEVICE: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device attribute, and one process
+// may drive several GPUs.
+struct DeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool first() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    return !(mask.fetch_or(bit) & bit);
+  }
+};
 
 // Live timing: one (start, stop) hipEvent pair around each launch, on the launch stream.
 struct ProfScope {

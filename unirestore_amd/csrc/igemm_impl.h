@@ -441,9 +441,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
 // ab[b] = LDS byte address of activation fragment b at k-step 0 (row * 128 + ((lane half ^ swizzle) << 4)), aw = the same for the
 // wave's first weight fragment (fragment a: + a * 4096); rows are 128-byte, 128-aligned, slots XOR-swizzled with (row >> 1) & 7.
 #if UR_IGASM_ABL == 4
-#include "igemm_asm_abl4.inc"
+#include "../../tools/ab/igemm_asm_abl4.inc"
 #elif UR_IGASM_ABL == 5
-#include "igemm_asm_abl5.inc"
+#include "../../tools/ab/igemm_asm_abl5.inc"
 #else
 #include "igemm_asm.inc"
 #endif
@@ -928,11 +928,10 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }     // row-stat planes this launch writes
   constexpr int lds = 2 * (BM + BN) * 128;
   static_assert(epi_lds_bytes<BM, BN, 256>() <= lds, "epilogue staging must fit the K ring");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, false, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, true, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
   static const bool no_g1 = getenv("UR_IGEMM_NOG1") != nullptr;
@@ -1293,10 +1292,9 @@ int launch_gemm(ConvK& k, hipStream_t s) {
   constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = epi_lds_bytes<BM, BN, WM * WN * 64, PAIRC>();
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
   }
   UR_F16_SWITCH(k, hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC, F16>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k));
   return ur::check_launch("ur_conv2d_nhwc");
@@ -1320,10 +1318,9 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
   constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = epi_lds_bytes<BM, BN, WM * WN * 64>();
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, WM, WN, NST, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
   UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, WM, WN, NST, F16>), grid, dim3(WM * WN * 64), lds, s, k));
@@ -2024,13 +2021,12 @@ int launch_halo(ConvK& k, hipStream_t s) {
   set_gn_plan(k, true, (k.OH / TH) * (k.OW / 32));         // a patch never leaves its image: one partial per patch
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
   k.patch_tw = 32;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_ws_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_ws_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
   }
   static const bool no_ws = getenv("UR_HALO_NOWS") != nullptr;          // A/B: every wave loads for itself (rounds 1-2 structure)
   if (no_ws) {
@@ -2279,11 +2275,10 @@ int launch_halo_img(ConvK& k, hipStream_t s) {
   k.nk_per_split = cps * 9;
   set_gn_plan(k, (k.OHW % BM) == 0, k.OHW / BM);
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
   }
   if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
   else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));

@@ -29,9 +29,9 @@
 #define UR_CHAIN_ABL 0      // timing-only ablations for A/B builds (tools/bench_chain.py): 1 = no MFMA phases, 2 = no weight DMA, 3 = no GELU,
 #endif                      // 4 = MFMA phases without their fragment reads, 5 = without their MFMAs, 6 = cycle stamps of one FF chunk
 #if UR_CHAIN_ABL == 4
-#include "tchain_asm_abl4.inc"
+#include "../../tools/ab/tchain_asm_abl4.inc"
 #elif UR_CHAIN_ABL == 5
-#include "tchain_asm_abl5.inc"
+#include "../../tools/ab/tchain_asm_abl5.inc"
 #else
 #include "tchain_asm.inc"
 #endif
@@ -419,10 +419,9 @@ __global__ __launch_bounds__(256, 1) void tchain_mlp_kernel(const MlpP p) {
 
 template <bool F16>
 int launch_mlp(const MlpP& p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&tchain_mlp_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
-    attr_set = true;
   }
   hipLaunchKernelGGL((tchain_mlp_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);
   return ur::check_launch("ur_ff_geglu_fused");
@@ -752,30 +751,27 @@ __global__ __launch_bounds__(256, 1) void tchain_tail_kernel(const TailP p) {
 
 template <bool F16>
 int launch_head(const HeadP& p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&tchain_head_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
-    attr_set = true;
   }
   hipLaunchKernelGGL((tchain_head_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);
   return ur::check_launch("ur_transformer_head_fused");
 }
 template <bool F16>
 int launch_csce(const CsceP& p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&tchain_csce_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
-    attr_set = true;
   }
   hipLaunchKernelGGL((tchain_csce_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);
   return ur::check_launch("ur_csce_fused");
 }
 template <bool F16>
 int launch_tail(const TailP& p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&tchain_tail_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
-    attr_set = true;
   }
   hipLaunchKernelGGL((tchain_tail_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);
   return ur::check_launch("ur_transformer_tail_fused");

@@ -36,12 +36,15 @@ class CSCEAdapter(nn.Module):
     def run(self, x, condition):
         n, hh, ww, c = x.shape
         if (_nn.CHAIN and c == chain.CHAIN_C and condition.shape[-1] == 256 and self.tuner["0"].out_channels == c and
-                (hh * ww) % chain.CHAIN_TOK == 0 and x.is_contiguous() and condition.is_contiguous()):
+                (hh * ww) % chain.CHAIN_TOK == 0 and x.is_contiguous() and condition.is_contiguous() and
+                tuple(condition.shape[:3]) == (n, hh, ww) and condition.dtype == x.dtype):
             key = ("cache", "chain", ops.act_dtype())          # one launch: the token-stationary chain (csrc/tchain.hip, kind CSCE)
             if key not in self.__dict__:
                 self.__dict__[key] = chain.pack_csce(self.proj.weight, self.proj.bias, self.tuner["0"].weight, self.tuner["0"].bias,
                                                      self.tuner["2"].weight, self.tuner["2"].bias, DEV)
             return chain.csce_fused(x, condition, self.__dict__[key])
+        if tuple(condition.shape[:3]) != (n, hh, ww):
+            raise ValueError(f"CSCEAdapter: condition {tuple(condition.shape)} does not cover x {tuple(x.shape)}")
         s = ops.conv(condition, self.proj.packed(), residual=x)               # s = x + proj(cond)
         h = ops.conv(s, self.tuner["0"].packed(), act=UR_ACT_GELU)
         return ops.conv(h, self.tuner["2"].packed(), residual=s, gn=True)     # tuner(s) + s (feeds a GroupNorm in the up path)
