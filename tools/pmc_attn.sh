@@ -23,8 +23,13 @@ if not fs: print("no output for: $C")
 else:
     agg=collections.defaultdict(float); cnt=collections.Counter()
     for r in csv.DictReader(open(fs[0])):
-        if "attn_fwd" in r["Kernel_Name"]: agg[r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[r["Counter_Name"]]+=1
+        if "attn_" in r["Kernel_Name"]: agg[r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[r["Counter_Name"]]+=1
     print({a: round(b/cnt[a]) for a,b in agg.items()}, "launches", max(cnt.values()) if cnt else 0)
 PY
 done
+rm -rf gpurun_out/pmc1
+# kernel duration from a plain kernel trace (un-profiled clocks differ: compare like with like)
+rm -rf gpurun_out/pmc1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc1 -o p -- python /tmp/attn_run.py > /dev/null 2>&1
+grep -h "attn_" gpurun_out/pmc1/*kernel_stats.csv | head -3
 rm -rf gpurun_out/pmc1

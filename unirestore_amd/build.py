@@ -18,6 +18,7 @@ IGEMM_UNITS = ["igemm_v2.hip", "igemm_halo.hip", "igemm_v1a.hip", "igemm_v1b.hip
 # (source, extra flags, object name): every igemm instantiation unit is built once per 16-bit type
 SOURCES = [(u, [f"-DUR_TU_F16={t}"], u.replace(".hip", "_f16.o" if t else "_bf16.o")) for u in IGEMM_UNITS for t in (0, 1)] + \
           [("attention.hip", [f"-DUR_TU_F16={t}"], "attention_f16.o" if t else "attention_bf16.o") for t in (0, 1)] + \
+          [("attention_pp.hip", [f"-DUR_TU_F16={t}"], "attention_pp_f16.o" if t else "attention_pp_bf16.o") for t in (0, 1)] + \
           [("attention512.hip", [f"-DUR_TU_F16={t}"], "attention512_f16.o" if t else "attention512_bf16.o") for t in (0, 1)] + \
           [(u, [], u.replace(".hip", ".o")) for u in ("tchain.hip", "igemm.hip", "norms.hip", "elementwise.hip", "runtime.hip")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
@@ -54,7 +55,7 @@ def build(force=False, verbose=True):
         if src.startswith("igemm"):
             deps += [os.path.join(CSRC, "igemm_impl.h"), os.path.join(CSRC, "igemm_asm.inc")]
         if src.startswith("attention"):
-            deps.append(os.path.join(CSRC, "attention_params.h"))
+            deps += [os.path.join(CSRC, "attention_params.h"), os.path.join(CSRC, "attention_pp_asm.inc")]
         if src.startswith("tchain"):
             deps.append(os.path.join(CSRC, "tchain_asm.inc"))
         newest = max(os.path.getmtime(d) for d in deps)

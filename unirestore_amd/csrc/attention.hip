@@ -11,6 +11,7 @@
 //     XOR-swizzled LDS (2 stages, one barrier per tile); swizzles verified by tools/lds_conflicts.py.
 #include "common.h"
 #include "attention_params.h"
+#include <cstdlib>
 
 // 128 B of zeros: source of out-of-range 16-byte pieces for the LDS-DMA loader
 static __device__ uint4 g_attn_zero_page[8];
@@ -259,6 +260,8 @@ int ur_attn_launch_bf16(const void* pp, int D, hipStream_t s);
 int ur_attn_launch_f16(const void* pp, int D, hipStream_t s);
 int ur_attn512_launch_bf16(const void* pp, hipStream_t s);
 int ur_attn512_launch_f16(const void* pp, hipStream_t s);
+int ur_attn_pp_launch_bf16(const void* pp, hipStream_t s);      // attention_pp.hip
+int ur_attn_pp_launch_f16(const void* pp, hipStream_t s);
 
 int UR_ATTN_LAUNCH(const void* pp, int D, hipStream_t s) {
   const AttnP& p = *static_cast<const AttnP*>(pp);
@@ -291,12 +294,21 @@ extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, vo
   p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.vt = (const uint16_t*)vt; p.o = (uint16_t*)o;
   p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
   p.bs_q = bs_q; p.bs_k = bs_k; p.bs_vt = bs_vt; p.bs_o = bs_o;
-  p.scale_log2e = scale * 1.4426950408889634f;
+  p.scale_log2e = (float)((double)scale * 1.4426950408889634);      // (scale = ln 2 gives exactly 1: q arrives pre-scaled)
   hipStream_t s = (hipStream_t)stream;
   const double flops = 4.0 * B * H * (double)Tq * Tk * D;
   const double bytes = 2.0 * B * H * ((double)Tq * D * 2 + (double)Tk * D * 2);
   ur::ProfScope prof("attention", flops, bytes, s);
   if (D == 512) return dtype == UR_DT_F16 ? ur_attn512_launch_f16(&p, s) : ur_attn512_launch_bf16(&p, s);     // attention512.hip
+  // self-attention shapes: the ping-pong kernel (attention_pp.hip: 256 queries per workgroup, one workgroup per CU) when its
+  // grid fills whole rounds of the 256 CUs well enough (640 workgroups = 2.5 rounds: 203 us against 229; 320 = 1.25 rounds:
+  // 42 against 39 us for the 128-query kernel below).  UR_ATTN_NOPP=1 keeps the round-1 kernel everywhere (A/B, tests).
+  static const bool nopp = getenv("UR_ATTN_NOPP") && atoi(getenv("UR_ATTN_NOPP")) != 0;
+  if (D == 64 && Tq % 256 == 0 && Tk % 256 == 0 && !nopp) {
+    const long long wgs = (long long)(Tq / 256) * B * H, rounds = (wgs + 255) / 256;
+    if (wgs <= 256 || wgs * 4 >= rounds * 256 * 3)
+      return dtype == UR_DT_F16 ? ur_attn_pp_launch_f16(&p, s) : ur_attn_pp_launch_bf16(&p, s);
+  }
   return dtype == UR_DT_F16 ? ur_attn_launch_f16(&p, D, s) : ur_attn_launch_bf16(&p, D, s);
 }
 #endif

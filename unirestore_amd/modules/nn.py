@@ -214,26 +214,40 @@ class _ToOut(nn.ModuleList):
         super().__init__([Linear(c, c), nn.Identity()])
 
 
-def _fused_qkv(mod, names):
-    ck = ("cache", "qkv", ops.act_dtype())
+# Softmax scale folded into the query projection.  The d = 64 attention kernels work in the exp2 domain on scores that are already
+# multiplied by scale * log2(e) (csrc/attention_pp.hip: the subtraction of the running maximum is the MFMA's C operand, so a
+# per-score multiply would be the only arithmetic left in front of the exponential).  Folding the factor into the fp32 master of
+# to_q BEFORE its one rounding to 16 bits costs no accuracy; the kernel's own fallback - multiply the 16-bit q by the factor and
+# round again - does (bf16: a second 2^-9 rounding of every q element).  ur_attention_fwd is then called with scale = ln 2, i.e.
+# scale * log2(e) = 1.
+Q_FOLD = math.log2(math.e)
+LN2 = math.log(2.0)
+
+
+def _scaled_first(ts, q_scale):
+    ts = [None if t is None else t.detach().float() for t in ts]
+    if q_scale != 1.0 and ts[0] is not None:
+        ts[0] = ts[0] * q_scale
+    return ts
+
+
+def _fused_qkv(mod, names, q_scale=1.0):
+    ck = ("cache", "qkv", ops.act_dtype(), q_scale)
     if ck not in mod.__dict__:
-        ws = [getattr(mod, n).weight for n in names]
-        bs = [getattr(mod, n).bias for n in names]
-        w = torch.cat([t.detach().float() for t in ws], 0)
-        b = None if bs[0] is None else torch.cat([t.detach().float() for t in bs], 0)
-        mod.__dict__[ck] = ops.pack_conv(w, b, DEV)
+        ws = _scaled_first([getattr(mod, n).weight for n in names], q_scale)
+        bs = _scaled_first([getattr(mod, n).bias for n in names], q_scale)
+        mod.__dict__[ck] = ops.pack_conv(torch.cat(ws, 0), None if bs[0] is None else torch.cat(bs, 0), DEV)
     return mod.__dict__[ck]
 
 
-def _fused_ln(mod, key, names, norm, pair=False):
+def _fused_ln(mod, key, names, norm, pair=False, q_scale=1.0):
     """Linear(LayerNorm(x)) weights folded for the LN-fused GEMM epilogue (cached): rows = cat of `names`."""
-    ck = ("cache", "ln", key, ops.act_dtype())
+    ck = ("cache", "ln", key, ops.act_dtype(), q_scale)
     if ck not in mod.__dict__:
-        ws = [getattr(mod, n).weight.detach().float() for n in names]
-        bs = [getattr(mod, n).bias for n in names]
-        w = torch.cat(ws, 0)
-        b = None if bs[0] is None else torch.cat([t.detach().float() for t in bs], 0)
-        mod.__dict__[ck] = ops.pack_linear_ln(w, b, norm.weight, norm.bias, norm.eps, DEV, pair=pair)
+        ws = _scaled_first([getattr(mod, n).weight for n in names], q_scale)
+        bs = _scaled_first([getattr(mod, n).bias for n in names], q_scale)
+        mod.__dict__[ck] = ops.pack_linear_ln(torch.cat(ws, 0), None if bs[0] is None else torch.cat(bs, 0), norm.weight, norm.bias, norm.eps,
+                                               DEV, pair=pair)
     return mod.__dict__[ck]
 
 
@@ -249,12 +263,14 @@ def self_attention(mod, h, heads, residual, gn_kw={}, ln=None, rows=False):
     ldvt = ops.round_up(t, 8)
     vt = torch.zeros((b, c, ldvt), dtype=h.dtype, device=h.device) if ldvt != t else \
         torch.empty((b, c, ldvt), dtype=h.dtype, device=h.device)
+    scale = 1.0 / math.sqrt(d)
+    qs = scale * Q_FOLD if d == 64 else 1.0           # d = 64: to_q carries scale * log2(e) (see Q_FOLD above)
     if ln is not None:
-        qk = ops.linear(h, _fused_ln(mod, "qkv", ("to_q", "to_k", "to_v"), ln[0]), ln_stats=ln[1], yt=vt, n_split=2 * c, t_rows=t)
+        qk = ops.linear(h, _fused_ln(mod, "qkv", ("to_q", "to_k", "to_v"), ln[0], q_scale=qs), ln_stats=ln[1], yt=vt, n_split=2 * c, t_rows=t)
     else:
-        qk = ops.linear(h, _fused_qkv(mod, ("to_q", "to_k", "to_v")), yt=vt, n_split=2 * c, t_rows=t)   # [B,T,3C] (V cols unused)
+        qk = ops.linear(h, _fused_qkv(mod, ("to_q", "to_k", "to_v"), q_scale=qs), yt=vt, n_split=2 * c, t_rows=t)   # [B,T,3C] (V cols unused)
     if d in (64, 128) or (d == 512 and not NO_FLASH512):
-        o = ops.attention(qk, qk[:, :, c:], vt, heads, d, t, t, 1.0 / math.sqrt(d), ldq=3 * c, ldk=3 * c,
+        o = ops.attention(qk, qk[:, :, c:], vt, heads, d, t, t, LN2 if d == 64 else scale, ldq=3 * c, ldk=3 * c,
                           bs_q=t * 3 * c, bs_k=t * 3 * c, bs_vt=c * ldvt, batch=b)
     else:
         o = attention_gemm(qk[:, :, :c], qk[:, :, c:2 * c], vt, heads, d, t)
@@ -381,8 +397,9 @@ class Transformer2DModel(nn.Module):
         if key not in self.__dict__:
             b = self.transformer_blocks[0]
             ff1, ff2 = b.ff.net[0].proj, b.ff.net[2]
-            head = chain.pack_head(self.proj_in.weight, self.proj_in.bias, b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight,
-                                   b.norm1.weight, b.norm1.bias, DEV)
+            qs = Q_FOLD / math.sqrt(self.proj_in.weight.shape[0] // b.attn1.heads)          # softmax scale * log2(e) folded into to_q
+            head = chain.pack_head(self.proj_in.weight, self.proj_in.bias, b.attn1.to_q.weight.detach().float() * qs, b.attn1.to_k.weight,
+                                   b.attn1.to_v.weight, b.norm1.weight, b.norm1.bias, DEV)
             tail = chain.pack_tail(b.attn1.to_out[0].weight, b.attn1.to_out[0].bias, b.attn2.to_q.weight, b.norm2.weight, b.norm2.bias,
                                    b.attn2.to_k.weight, b.attn2.to_v.weight, ctx[0].float(), b.attn2.to_out[0].weight, b.attn2.to_out[0].bias,
                                    ff1.weight, ff1.bias, ff2.weight, ff2.bias, b.norm3.weight, b.norm3.bias,
@@ -407,7 +424,7 @@ class Transformer2DModel(nn.Module):
             t, heads = hh * ww, b.attn1.heads
             d = c // heads
             h0, q, k, vt = chain.transformer_head_fused(x, self.norm.coeffs(x), head, n, b.norm1.eps)
-            o1 = ops.attention(q, k, vt, heads, d, t, t, 1.0 / math.sqrt(d), ldq=c, ldk=c, bs_q=t * c, bs_k=t * c, bs_vt=c * t, batch=n)
+            o1 = ops.attention(q, k, vt, heads, d, t, t, LN2, ldq=c, ldk=c, bs_q=t * c, bs_k=t * c, bs_vt=c * t, batch=n)   # (q pre-scaled)
             y = chain.transformer_tail_fused(o1, h0, x, tail, n, 4 * c, heads, ctx.shape[1], b.norm1.eps, 1.0 / math.sqrt(d))
             return ops.carry(y, y.view(n, hh, ww, c))
         h = ops.linear(self.norm.run(x).view(n, hh * ww, c), self.proj_in.packed(), rows=FUSE_LN)
