@@ -101,20 +101,24 @@ def test_ctypes_struct_layout_matches_the_header(tmp_path):
 
 
 def test_generated_asm_blocks_are_current(tmp_path):
-    """csrc/tchain_asm.inc, csrc/igemm_asm.inc and their timing-only variants tools/ab/*_abl{4,5}.inc are GENERATED
-    (tools/gen_chain_asm.py, tools/gen_igemm_asm.py): the committed files must be exactly what the generators emit."""
+    """csrc/tchain_asm.inc, csrc/igemm_asm.inc, csrc/attention_pp_asm.inc and the timing-only variants tools/ab/*_abl{4,5}.inc are
+    GENERATED (tools/gen_chain_asm.py, tools/gen_igemm_asm.py, tools/gen_attn_asm.py): the committed files must be exactly what
+    the generators emit (with no ATTN_* environment switches set)."""
     import importlib.util
     import shutil
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tools = tmp_path / "tools"
     out = tmp_path / "unirestore_amd" / "csrc"
     tools.mkdir(parents=True); out.mkdir(parents=True); (tools / "ab").mkdir()
-    for f in ("gen_chain_asm.py", "gen_igemm_asm.py"):
+    for f in ("gen_chain_asm.py", "gen_igemm_asm.py", "gen_attn_asm.py"):
         shutil.copy(os.path.join(root, "tools", f), tools / f)
     import sys
     sys.path.insert(0, str(tools))
+    for k in [k for k in os.environ if k.startswith("ATTN_")]:
+        del os.environ[k]
+    argv, sys.argv = sys.argv, ["gen"]                       # (gen_attn_asm.py takes an optional output path)
     try:
-        for mod in ("gen_chain_asm", "gen_igemm_asm"):
+        for mod in ("gen_chain_asm", "gen_igemm_asm", "gen_attn_asm"):
             sys.modules.pop(mod, None)
             spec = importlib.util.spec_from_file_location(mod, str(tools / (mod + ".py")))
             m = importlib.util.module_from_spec(spec)
@@ -122,11 +126,12 @@ def test_generated_asm_blocks_are_current(tmp_path):
             spec.loader.exec_module(m)
             m.main()
     finally:
+        sys.argv = argv
         sys.path.remove(str(tools))
-        for mod in ("gen_chain_asm", "gen_igemm_asm"):
+        for mod in ("gen_chain_asm", "gen_igemm_asm", "gen_attn_asm"):
             sys.modules.pop(mod, None)
     made = sorted(os.listdir(out))
-    assert made == ["igemm_asm.inc", "tchain_asm.inc"]
+    assert made == ["attention_pp_asm.inc", "igemm_asm.inc", "tchain_asm.inc"]
     for f in made:
         assert (out / f).read_text() == open(os.path.join(root, "unirestore_amd", "csrc", f)).read(), f
     made_ab = sorted(os.listdir(tools / "ab"))

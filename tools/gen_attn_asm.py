@@ -9,14 +9,23 @@ scheduled: 179.5 us on the 4 x 4096 x 4096 x 64 shape against 173.4 for the roun
 
 Structure (one workgroup = 8 waves = groups A (waves 0-3) and B (waves 4-7), one wave of each per SIMD, 32 queries per wave):
 
-    phase 2t     A: softmax(t)                          B: P.V(t-1), K.Q^T(t)
-    phase 2t+1   A: DMA(t+1), P.V(t), K.Q^T(t+1)        B: DMA(t+1), softmax(t)
-    s_barrier after every phase; each wave waits for its own DMA pieces (vmcnt(0)) in front of the barrier that ends phase 2t+2
+    phase 2t     A: softmax(t), V^T fragment prefetch      B: P.V(t-1) + K.Q^T(t) interleaved, DMA of stage t+2
+    phase 2t+1   A: P.V(t) + K.Q^T(t+1), DMA of stage t+3  B: softmax(t), prefetch
+    s_barrier after every phase; a wave waits for its own older DMA pieces (vmcnt(2)) at the end of its softmax phase
 
-  stage s = { V^T(s) | K(s+1) } (16 KiB) lives in LDS buffer s & 1; the loop is unrolled by two so every LDS offset is an
-  immediate.  Softmax fast path per 32 scores: 32 v_exp_f32 + 32 v_add_f32 + 16 v_cvt_pk + 4; the S accumulators start at -m (the
-  MFMA's C operand), so there is no subtraction and no maximum: the lane's partial row sum proves p < 2^14, else the slow path
+  stage s = { V^T(s) | K(s+1) } (16 KiB) lives in LDS buffer s & 3; the loop is unrolled by four so every LDS offset is an
+  immediate.  MFMA phase: P.V and K.Q^T alternate (four independent accumulator chains), fragments through an 8-slot register
+  ring with counted lgkmcnt, the first four reads issued in front of the phase barrier, the two DMA pieces of stage t+3 behind
+  MFMAs 3 and 9.  Softmax fast path per 32 scores: 32 v_exp_f32 + 32 v_add_f32 + 16 v_cvt_pk + 4; the S accumulators start at -m
+  (the MFMA's C operand), so there is no subtraction and no maximum: the lane's partial row sum proves p < 2^14, else the slow path
   (maximum, new reference, O / l rescale, recompute) runs - always at tile 0.
+
+Measured on the way (4 x 4096 x 4096 x 64 launch = 2 full rounds of workgroups, us; round-1 kernel 173.4): two LDS buffers, DMA
+in the phases, all fragment reads behind the barrier 146.4; four buffers + prefetch 141.8; interleaved chains 143.3 (no change:
+the chains were not the limit); v_pk_add_f32 row sums 154.4, v_dot2c 158.7 (both slower than scalar adds); DMA placement (softmax
+phase start / inside the exponentials / behind MFMAs) 142.2 / 145.9 / 142.1.  In-kernel timers (ATTN_DBG=1): softmax phase ~840
+cycles (707 without the partner's MFMAs: 32 x ~10 for the exponentials + 64 x 4 + overhead), MFMA phase ~740 (512 of MFMA), clock
+1.87 GHz; without any barrier the same work takes 1600 instead of 2012 cycles per tile - and the clock drops to 1.67 GHz.
 
 Operand numbering: see OPERANDS below (outputs = SGPR temporaries first, then the inputs).  Macro arguments: MFMA mnemonic,
 16-bit pack mnemonic (bf16 / f16 objects share the schedule).
@@ -53,6 +62,7 @@ P = alloc(16)          # packed P^T: key step kk at P + 4 kk
 KA = alloc(8, 1)       # K fragment addresses: KA + 4 f + ds
 VA = alloc(8, 1)       # V^T fragment addresses: VA + 4 f + kk
 TMP = alloc(8)
+E = alloc(32) if int(os.environ.get("ATTN_LATE_CVT", "0")) else None     # fp32 exp2 results kept for the late packing (LATE_CVT)
 PS0 = alloc(2, 2)
 PS1 = PS0 + 1
 PSUM, LRUN, MC, MX, DLT, ALPHA = (alloc(1, 1) for _ in range(6))
@@ -68,6 +78,11 @@ def v(i, n=1):
 # the 16-bit weights the P.V MFMA multiplies
 SUM_MODE = os.environ.get("ATTN_SUM", "add")
 PK_ADD = SUM_MODE == "pk"
+# ATTN_LATE_CVT=1: the 16-bit packing of P for key steps 1-3 (12 of the 16 v_cvt_pk) moves from the softmax phase - the longer of
+# the two - into the wave's own MFMA phase, four packs in front of each key step's first P.V MFMA.  Measured: no gain (143.4 vs
+# 143.0 us; the softmax phase is bound by the 32 v_exp_f32 at ~10 cycles each, not by its instruction count) and it needs an
+# s_nop between the pack and the MFMA that reads it (VALU write -> MFMA source: a real hazard, 16 red tests without it). Off.
+LATE_CVT = int(os.environ.get("ATTN_LATE_CVT", "0"))
 TILE = 8192
 STAGE = 16384
 SUM_MAX = 0x46800000      # 2^14
@@ -164,6 +179,11 @@ def mfma_phase(p, buf, with_qk, dma=None):
         issued = min(n, NRING + i)
         p(f"s_waitcnt lgkmcnt({issued - (i + 1)})")
         slot = v(RING + 4 * (i % NRING), 4)
+        if kind == "pv" and LATE_CVT and PV[j][0] >= 1 and PV[j][1] == 0:        # first use of P for this key step: pack it now
+            for u in range(4):
+                q = 4 * PV[j][0] + u
+                p(f"@CVT@ {v(P + q)}, {v(E + 2 * q)}, {v(E + 2 * q + 1)}")
+            p("s_nop 1")           # VALU write -> MFMA source read
         if kind == "pv":
             kk, f = PV[j]
             p(f"@MN@ {v(O + 16 * f, 16)}, {slot}, {v(P + 4 * kk, 4)}, {v(O + 16 * f, 16)}")
@@ -193,28 +213,31 @@ def exp_sum_pack(p, src_sub=None, hooks=None):
     p(f"v_mov_b32 {v(PS1)}, 0")
     assert PS1 == PS0 + 1 and PS0 % 2 == 0 and TMP % 2 == 0
 
+    def tmp(i, h):
+        return (E + 2 * i + h) if LATE_CVT else (TMP + 2 * (i % 4) + h)
+
     def exps(i):
-        slot = i % 4
         for h in range(2):
             src = v(S + 2 * i + h)
-            dst = v(TMP + 2 * slot + h)
+            dst = v(tmp(i, h))
             if src_sub is not None:
                 p(f"v_sub_f32 {dst}, {src}, {v(src_sub)}")
                 src = dst
             p(f"@EXP@ {dst}, {src}")
 
     def fin(i):
-        slot = i % 4
+        t0, t1 = tmp(i, 0), tmp(i, 1)
         if PK_ADD:
-            p(f"v_pk_add_f32 {v(PS0, 2)}, {v(PS0, 2)}, {v(TMP + 2 * slot, 2)}")
+            p(f"v_pk_add_f32 {v(PS0, 2)}, {v(PS0, 2)}, {v(t0, 2)}")
         elif SUM_MODE == "dot2":
-            p(f"@CVT@ {v(P + i)}, {v(TMP + 2 * slot)}, {v(TMP + 2 * slot + 1)}")
+            p(f"@CVT@ {v(P + i)}, {v(t0)}, {v(t1)}")
             p(f"@DOT@ {v(PS0 + (i & 1))}, @ONES@, {v(P + i)}")
             return
         else:
-            p(f"v_add_f32 {v(PS0)}, {v(PS0)}, {v(TMP + 2 * slot)}")
-            p(f"v_add_f32 {v(PS1)}, {v(PS1)}, {v(TMP + 2 * slot + 1)}")
-        p(f"@CVT@ {v(P + i)}, {v(TMP + 2 * slot)}, {v(TMP + 2 * slot + 1)}")
+            p(f"v_add_f32 {v(PS0)}, {v(PS0)}, {v(t0)}")
+            p(f"v_add_f32 {v(PS1)}, {v(PS1)}, {v(t1)}")
+        if not LATE_CVT or i < 4:
+            p(f"@CVT@ {v(P + i)}, {v(t0)}, {v(t1)}")
 
     exps(0)
     for i in range(1, 16):

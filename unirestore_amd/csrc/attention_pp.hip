@@ -1,5 +1,5 @@
 // Ping-pong flash attention forward for head dim 64 on gfx950 (round 4): the kernel behind ur_attention_fwd for the
-// self-attention shapes (Tq % 256 == 0, Tk % 64 == 0); attention.hip keeps every other shape (cross-attention's 77 keys, d = 128).
+// self-attention shapes (Tq % 256 == 0, Tk % 256 == 0); attention.hip keeps every other shape (cross-attention's 77 keys, d = 128).
 //
 // Why a second kernel.  attn_fwd_kernel (attention.hip) runs 3 independent waves per SIMD through the same per-tile program
 // (QK^T MFMAs -> softmax VALU -> PV MFMAs -> barrier); its matrix pipe is busy 37.5 % of the time at the clock the part holds
@@ -15,8 +15,10 @@
 //     only a wave that fails the test (or is at tile 0) takes the slow path: maximum, new reference, O / l rescale, recompute.
 // Layout (as attention.hip): S^T = K.Q^T so a lane owns one query column; K rows read through the bit-2/3 swap so that the S
 // accumulator registers, packed pairwise, ARE the P^T B operand; V arrives transposed ([channel][key]); 64-key K / V^T tiles
-// land in XOR-swizzled LDS by buffer-descriptor LDS-DMA (one 1-KiB piece of each per wave and tile), two stage buffers
-// {V^T(t) | K(t+1)}, counted by hand: the DMA is invisible to hipcc, every wait is an explicit s_waitcnt in front of a barrier.
+// land in XOR-swizzled LDS by buffer-descriptor LDS-DMA (one 1-KiB piece of each per wave and tile), four stage buffers
+// {V^T(t) | K(t+1)} filled three tiles ahead, counted by hand.  The tile loop and the epilogue are ONE generated asm statement
+// with hand-owned registers (tools/gen_attn_asm.py -> attention_pp_asm.inc; its docstring has the schedule and the measurements);
+// this file computes what enters it: descriptors, per-lane offsets, the Q fragments, fragment addresses, the first stages' DMA.
 #include "common.h"
 #include "attention_params.h"
 #include <cstdlib>
@@ -44,15 +46,6 @@ __device__ __forceinline__ void pp_dma(unsigned m0v, unsigned voff, const pp_u32
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(rs),
                "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
 }
-#define PP_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define PP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-template <bool F16> __device__ __forceinline__ uint32_t pp_pack2(float a, float b) {      // round-to-nearest-even, NOT saturating:
-  f32x2_t v = {a, b};                                                                      // P < 2^14 by construction
-  if constexpr (F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
-  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-}
-
 #define ATTN_PP_ASM_SEL ATTN_PP_ASM
 
 template <bool F16>
@@ -121,7 +114,7 @@ __global__ __launch_bounds__(512) void attn_pp64_kernel(const AttnP p) {
     va[f] = vr * 128 + ((hf ^ ((vr >> 1) & 7)) << 4);
   }
 
-  // ---- tile loop + epilogue: one hand-scheduled asm statement (tools/gen_attn_asm.py; registers v96..v255 are its own) ----------
+  // ---- tile loop + epilogue: one hand-scheduled asm statement (tools/gen_attn_asm.py; the registers named in ATTN_PP_CLOBBERS are its own) ----------
   {
     uint16_t* optr = p.o + b * p.bs_o + (long long)(q0 + l31) * p.ldo + h * 64 + 4 * hf;
     const unsigned ldsb = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)wid * 1024u);
