@@ -175,6 +175,15 @@ int ur_softmax_rows_f32(const float* s, void* p, long long rows, int cols, int l
 int ur_attention_fwd(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk,
                      int D, int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k,
                      long long bs_vt, long long bs_o, float scale, int dtype, ur_stream_t stream);
+/* The same with a scratch buffer.  The d = 64 self-attention kernel runs one 256-query workgroup per CU; when the launch is
+ * whole rounds of the 256 CUs plus at most half a round (B = 8, 5 heads, T = 4096: 640 workgroups), the query tiles of that
+ * remainder are split in two key halves that fill the last round, and a second small kernel merges the halves from `ws`
+ * (un-normalised fp32 rows + running maximum + row sum).  ur_attention_workspace_bytes() is what the split needs (0: none);
+ * ws == NULL or a smaller buffer just runs unsplit.  The library never allocates: the caller owns ws (16-byte aligned). */
+size_t ur_attention_workspace_bytes(int B, int H, int Tq, int Tk, int D);
+int ur_attention_fwd_ws(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk,
+                        int D, int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k, long long bs_vt,
+                        long long bs_o, float scale, void* ws, size_t ws_bytes, int dtype, ur_stream_t stream);
 
 /* ---- token-stationary fused chains (csrc/tchain.hip) ----------------------------------------------
  * A wave keeps 32 tokens in registers through a whole chain of token-wise layers; the weights arrive as a pre-packed

@@ -111,6 +111,36 @@ def test_pp_attention_scale_folded_equals_scale_passed(ops):
     assert rel_l2(o.cpu(), ref) < 2 * TOL[dt]
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_pp_attention_key_split_last_round(ops, dt):
+    """B*H*(T/256) = 640 workgroups = 2.5 rounds of the 256 CUs: with a workspace the last 128 query tiles run as 256 key halves +
+    the merge kernel (ur_attention_fwd_ws); without one (ur_attention_fwd) unsplit.  Both must match fp64, and each other closely."""
+    from unirestore_amd.capi import lib
+    b, heads, t, d = 32, 5, 1024, 64
+    c = heads * d
+    assert lib.ur_attention_workspace_bytes(b, heads, t, t, d) == 128 * 2 * 256 * 68 * 4
+    assert lib.ur_attention_workspace_bytes(b, 4, t, t, d) == 0                     # 512 workgroups: whole rounds
+    g = torch.Generator().manual_seed(21)
+    q, k, v = (torch.randn(b, t, c, generator=g).to(dt).float() for _ in range(3))
+    k[3, 700, :d] = q[3, 40, :d] * 9                                                 # a reference jump inside the SECOND key half
+    k = k.to(dt).float()
+    ref = _ref(q, k, v, heads, d, 0.125)
+    o_split = _run(ops, q, k, v, heads, d, 0.125, dt)                                # ops.attention passes the workspace
+    qkv = torch.cat([q, k, torch.zeros_like(q)], -1).to(dt).cuda()
+    vt = v.transpose(1, 2).contiguous().to(dt).cuda()
+    o_plain = torch.empty_like(o_split)
+    rc = lib.ur_attention_fwd(qkv.data_ptr(), qkv[:, :, c:].data_ptr(), vt.data_ptr(), o_plain.data_ptr(), b, heads, t, t, d, 3 * c, 3 * c, t,
+                              c, t * 3 * c, t * 3 * c, c * t, t * c, 0.125, ops._dt(qkv), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_l2(o_split.cpu(), ref) < TOL[dt] and rel_l2(o_plain.cpu(), ref) < TOL[dt]
+    assert rel_l2(o_split.cpu(), o_plain.cpu()) < TOL[dt]
+    head_rows = o_split[:, :, :].view(b * t, c)
+    assert not torch.equal(o_split, o_plain)                                         # the split path really ran
+    assert torch.equal(o_split[:25], o_plain[:25])                                   # ... and only on the trailing tiles (tile 512 = image 25, head 3)
+    assert torch.equal(o_split, _run(ops, q, k, v, heads, d, 0.125, dt))             # bit-reproducible
+
+
 _CHILD = r"""
 import sys, math, torch
 sys.path.insert(0, {root!r})

@@ -37,7 +37,7 @@ import os
 # ---------------------------------------------------------------------------------------------------------- operands
 OUT_S = ["t", "first", "last", "vso", "kso"]                                                        # "=&s" temporaries
 IN_V = ["qf0", "qf1", "qf2", "qf3", "ka0", "ka1", "va0", "va1", "kvo", "vvo", "optr"]  # "v" inputs
-IN_S = ["rsk", "rsv", "kstep", "nt", "grp", "ldsb"]                                     # "s" inputs
+IN_S = ["rsk", "rsv", "kstep", "nt", "grp", "ldsb", "part"]                             # "s" inputs
 DBG = int(os.environ.get("ATTN_DBG", "0"))      # phase timers (tools/attn_phase_timers.py): 5 more SGPR temporaries, s_memtime into VCC
 if DBG:
     OUT_S += ["acc0", "acc1", "acc2", "acc3", "tprev", "cyc0", "rt0"]
@@ -429,6 +429,20 @@ def program():
     p(f"v_permlane32_swap_b32 {v(PSUM)}, {v(LRUN)}")
     p("s_nop 1")
     p(f"v_add_f32 {v(LRUN)}, {v(LRUN)}, {v(PSUM)}")
+    # partial mode (this workgroup saw half of the keys): the un-normalised fp32 row + (m, l) go to the workspace, rows of 68 floats
+    p(f"s_cmp_eq_u32 {OP['part']}, 1")
+    p(f"s_cbranch_scc0 {L('epi_full')}")
+    for f in range(2):
+        for g in range(4):
+            p(f"global_store_dwordx4 {OP['optr']}, {v(O + 16 * f + 4 * g, 4)}, off offset:{(f * 32 + 8 * g) * 4}")
+    p(f"v_mov_b32 {v(TMP)}, {v(MC)}")
+    p(f"v_mov_b32 {v(TMP + 1)}, {v(LRUN)}")
+    p("s_mov_b64 exec, 0xffffffff")                    # the lower half-wave's pointer is the row start
+    p("s_nop 1")
+    p(f"global_store_dwordx2 {OP['optr']}, {v(TMP, 2)}, off offset:256")
+    p("s_mov_b64 exec, -1")
+    p(f"s_branch {L('end')}")
+    p.label("epi_full")
     p("s_nop 0")
     p(f"v_rcp_f32 {v(ALPHA)}, {v(LRUN)}")
     p("s_nop 0")
@@ -443,6 +457,7 @@ def program():
         for g in range(4):
             d = S + 2 * (4 * f + g)
             p(f"global_store_dwordx2 {OP['optr']}, {v(d, 2)}, off offset:{(f * 32 + 8 * g) * 2}")
+    p.label("end")
     if DBG:          # lanes 0..31 overwrite the first 24 bytes of their output row with the wave's timers
         p("s_waitcnt vmcnt(0)")
         p("s_memtime vcc")

@@ -63,6 +63,8 @@ SIGNATURES = {
     "ur_layernorm_rows": (_I, [_P, _P, _P, _P, _LL, _I, _F, _I, _P]),
     "ur_softmax_rows_f32": (_I, [_P, _P, _LL, _I, _I, _I, _P]),
     "ur_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL, _F, _I, _P]),
+    "ur_attention_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "ur_attention_fwd_ws": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL, _F, _P, _SZ, _I, _P]),
     "ur_chain_tile_bytes": (_SZ, []),
     "ur_ff_geglu_fused": (_I, [_P, _P, _SZ, _P, _LL, _I, _I, _I, _I, _F, _I, _P]),
     "ur_transformer_head_fused": (_I, [_P, _P, _P, _SZ, _P, _P, _P, _P, _LL, _I, _I, _F, _I, _P]),

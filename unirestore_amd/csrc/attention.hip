@@ -260,8 +260,8 @@ int ur_attn_launch_bf16(const void* pp, int D, hipStream_t s);
 int ur_attn_launch_f16(const void* pp, int D, hipStream_t s);
 int ur_attn512_launch_bf16(const void* pp, hipStream_t s);
 int ur_attn512_launch_f16(const void* pp, hipStream_t s);
-int ur_attn_pp_launch_bf16(const void* pp, hipStream_t s);      // attention_pp.hip
-int ur_attn_pp_launch_f16(const void* pp, hipStream_t s);
+int ur_attn_pp_launch_bf16(const void* pp, size_t ws_bytes, hipStream_t s);      // attention_pp.hip
+int ur_attn_pp_launch_f16(const void* pp, size_t ws_bytes, hipStream_t s);
 
 int UR_ATTN_LAUNCH(const void* pp, int D, hipStream_t s) {
   const AttnP& p = *static_cast<const AttnP*>(pp);
@@ -282,33 +282,55 @@ int UR_ATTN_LAUNCH(const void* pp, int D, hipStream_t s) {
 }
 
 #if !UR_TU_F16
-extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk, int D,
-                                int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k, long long bs_vt,
-                                long long bs_o, float scale, int dtype, ur_stream_t stream) {
+// half-tile count the ping-pong launch would split (0: no workspace wanted) - one rule for the size query and the launch
+static long long pp_split_tiles(int B, int H, int Tq, int Tk, int D) {
+  if (D != 64 || Tq % 256 || Tk % 512) return 0;
+  const long long n = (long long)(Tq / 256) * B * H, r = n % 256;
+  return (n >= 512 && r > 0 && r <= 128) ? r : 0;
+}
+
+extern "C" size_t ur_attention_workspace_bytes(int B, int H, int Tq, int Tk, int D) {
+  return B > 0 && H > 0 && Tq > 0 && Tk > 0 ? (size_t)pp_split_tiles(B, H, Tq, Tk, D) * 2 * 256 * 68 * 4 : 0;
+}
+
+extern "C" int ur_attention_fwd_ws(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk, int D,
+                                   int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k, long long bs_vt,
+                                   long long bs_o, float scale, void* ws, size_t ws_bytes, int dtype, ur_stream_t stream) {
   UR_REQUIRE(q && k && vt && o, "null pointer");
   UR_REQUIRE(D == 64 || D == 128 || D == 512, "head dim must be 64, 128 or 512 (use the GEMM path otherwise)");
   UR_REQUIRE_DT(dtype);
   UR_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "empty problem");
   UR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Tk, "leading dims");
+  UR_REQUIRE(!ws || ((uintptr_t)ws & 15) == 0, "workspace must be 16-byte aligned");
   AttnP p;
   p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.vt = (const uint16_t*)vt; p.o = (uint16_t*)o;
   p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
   p.bs_q = bs_q; p.bs_k = bs_k; p.bs_vt = bs_vt; p.bs_o = bs_o;
   p.scale_log2e = (float)((double)scale * 1.4426950408889634);      // (scale = ln 2 gives exactly 1: q arrives pre-scaled)
+  p.n_full = 0; p.ws = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
   const double flops = 4.0 * B * H * (double)Tq * Tk * D;
   const double bytes = 2.0 * B * H * ((double)Tq * D * 2 + (double)Tk * D * 2);
   ur::ProfScope prof("attention", flops, bytes, s);
   if (D == 512) return dtype == UR_DT_F16 ? ur_attn512_launch_f16(&p, s) : ur_attn512_launch_bf16(&p, s);     // attention512.hip
   // self-attention shapes: the ping-pong kernel (attention_pp.hip: 256 queries per workgroup, one workgroup per CU) when its
-  // grid fills whole rounds of the 256 CUs well enough (640 workgroups = 2.5 rounds: 203 us against 229; 320 = 1.25 rounds:
-  // 42 against 39 us for the 128-query kernel below).  UR_ATTN_NOPP=1 keeps the round-1 kernel everywhere (A/B, tests).
+  // grid fills whole rounds of the 256 CUs well enough - counting a split last round (workspace given) as half a round.
+  // 640 workgroups = 2.5 rounds: 203 us unsplit against 229 for the 128-query kernel below; 320 = 1.25 rounds unsplit: 42 against
+  // 39 us.  UR_ATTN_NOPP=1 keeps the round-1 kernel everywhere (A/B, tests).
   static const bool nopp = getenv("UR_ATTN_NOPP") && atoi(getenv("UR_ATTN_NOPP")) != 0;
   if (D == 64 && Tq % 256 == 0 && Tk % 256 == 0 && !nopp) {
-    const long long wgs = (long long)(Tq / 256) * B * H, rounds = (wgs + 255) / 256;
-    if (wgs <= 256 || wgs * 4 >= rounds * 256 * 3)
-      return dtype == UR_DT_F16 ? ur_attn_pp_launch_f16(&p, s) : ur_attn_pp_launch_bf16(&p, s);
+    const long long wgs = (long long)(Tq / 256) * B * H;
+    const long long r = ws && ws_bytes >= ur_attention_workspace_bytes(B, H, Tq, Tk, D) ? pp_split_tiles(B, H, Tq, Tk, D) : 0;
+    const double rounds = r ? (double)(wgs - r) / 256 + 0.5 : (double)((wgs + 255) / 256);
+    if (wgs <= 256 || wgs >= rounds * 256 * 0.75)
+      return dtype == UR_DT_F16 ? ur_attn_pp_launch_f16(&p, ws_bytes, s) : ur_attn_pp_launch_bf16(&p, ws_bytes, s);
   }
   return dtype == UR_DT_F16 ? ur_attn_launch_f16(&p, D, s) : ur_attn_launch_bf16(&p, D, s);
+}
+
+extern "C" int ur_attention_fwd(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk, int D,
+                                int ldq, int ldk, int ldvt, int ldo, long long bs_q, long long bs_k, long long bs_vt,
+                                long long bs_o, float scale, int dtype, ur_stream_t stream) {
+  return ur_attention_fwd_ws(q, k, vt, o, B, H, Tq, Tk, D, ldq, ldk, ldvt, ldo, bs_q, bs_k, bs_vt, bs_o, scale, nullptr, 0, dtype, stream);
 }
 #endif

@@ -60,13 +60,20 @@ __global__ __launch_bounds__(512) void attn_pp64_kernel(const AttnP p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;
   const int l31 = lane & 31, hf = lane >> 5;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * 256 + wid * 32;
-  const int nt = p.Tk >> 6;
+  // work item: a (batch-head, query tile) with all keys, or - behind the n_full whole ones - one key half of such a tile
+  const int wg = blockIdx.x, nq = p.Tq >> 8;
+  const int half = wg < p.n_full ? -1 : ((wg - p.n_full) & 1);
+  // workgroup b runs on XCD b % 8: every XCD gets a contiguous range of tiles, so the query tiles of one head share one L2
+  // (141.9 -> 136.8 us on the 4-head launch against the plain order)
+  const int tile = wg < p.n_full ? ((p.n_full & 7) == 0 ? (wg & 7) * (p.n_full >> 3) + (wg >> 3) : wg) : p.n_full + ((wg - p.n_full) >> 1);
+  const int bh = tile / nq, qt = tile - bh * nq, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = qt * 256 + wid * 32;
+  const int nt = half < 0 ? (p.Tk >> 6) : (p.Tk >> 7);
+  const int kt0 = half > 0 ? nt : 0;                          // first key tile of this work item
 
   const uint16_t* Q = p.q + b * p.bs_q + h * 64;
-  const uint16_t* K = p.k + b * p.bs_k + h * 64;
-  const uint16_t* V = p.vt + b * p.bs_vt + (long long)h * 64 * p.ldvt;
+  const uint16_t* K = p.k + b * p.bs_k + h * 64 + (long long)kt0 * 64 * p.ldk;
+  const uint16_t* V = p.vt + b * p.bs_vt + (long long)h * 64 * p.ldvt + kt0 * 64;
 
   // ---- LDS-DMA bookkeeping: wave w moves piece w (8 rows) of every K and V^T tile -----------------------------------------
   const pp_u32x4 rs_k = pp_rsrc(K), rs_v = pp_rsrc(V);
@@ -116,7 +123,10 @@ __global__ __launch_bounds__(512) void attn_pp64_kernel(const AttnP p) {
 
   // ---- tile loop + epilogue: one hand-scheduled asm statement (tools/gen_attn_asm.py; the registers named in ATTN_PP_CLOBBERS are its own) ----------
   {
-    uint16_t* optr = p.o + b * p.bs_o + (long long)(q0 + l31) * p.ldo + h * 64 + 4 * hf;
+    // output row of the lane: the 16-bit tensor, or (key halves) a 68-float workspace row = 64 fp32 channels | m | l | pad
+    uint16_t* optr = half < 0 ? p.o + b * p.bs_o + (long long)(q0 + l31) * p.ldo + h * 64 + 4 * hf
+                              : reinterpret_cast<uint16_t*>(p.ws + ((long long)(wg - p.n_full) * 256 + wid * 32 + l31) * 68 + 4 * hf);
+    const unsigned part_s = __builtin_amdgcn_readfirstlane(half < 0 ? 0u : 1u);
     const unsigned ldsb = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)wid * 1024u);
     const unsigned nt_s = __builtin_amdgcn_readfirstlane((unsigned)nt), grp_s = __builtin_amdgcn_readfirstlane((unsigned)grp);
     const unsigned kstep_s = __builtin_amdgcn_readfirstlane(kstep);
@@ -134,16 +144,43 @@ __global__ __launch_bounds__(512) void attn_pp64_kernel(const AttnP p) {
       asm volatile(ATTN_PP_ASM_SEL("v_mfma_f32_32x32x16_f16", "v_cvt_pk_f16_f32", "v_dot2c_f32_f16", "0x3c003c00")
                    : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4) PP_DBG_OUT
                    : "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(ka_a[0]), "v"(ka_a[1]), "v"(va_a[0]), "v"(va_a[1]), "v"(kvo), "v"(vvo),
-                     "v"(optr), "s"(rs_k), "s"(rs_v), "s"(kstep_s), "s"(nt_s), "s"(grp_s), "s"(ldsb)
+                     "v"(optr), "s"(rs_k), "s"(rs_v), "s"(kstep_s), "s"(nt_s), "s"(grp_s), "s"(ldsb), "s"(part_s)
                    : ATTN_PP_CLOBBERS);
     } else {
       asm volatile(ATTN_PP_ASM_SEL("v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32", "v_dot2c_f32_bf16", "0x3f803f80")
                    : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4) PP_DBG_OUT
                    : "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(ka_a[0]), "v"(ka_a[1]), "v"(va_a[0]), "v"(va_a[1]), "v"(kvo), "v"(vvo),
-                     "v"(optr), "s"(rs_k), "s"(rs_v), "s"(kstep_s), "s"(nt_s), "s"(grp_s), "s"(ldsb)
+                     "v"(optr), "s"(rs_k), "s"(rs_v), "s"(kstep_s), "s"(nt_s), "s"(grp_s), "s"(ldsb), "s"(part_s)
                    : ATTN_PP_CLOBBERS);
     }
   }
+}
+
+// The two key halves of a split tile -> the 16-bit output: o = (w1 O1 + w2 O2) / (w1 l1 + w2 l2), w_i = 2^(m_i - max(m1, m2)).
+// One thread per (query row, 8 channels); fixed order, no atomics.
+template <bool F16>
+__global__ __launch_bounds__(256) void attn_pp_combine_kernel(const AttnP p, int n_split) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int c8 = (int)(g & 7);
+  const long long row = g >> 3;                              // tile-major: split tile index * 256 + row in tile
+  if (row >= (long long)n_split * 256) return;
+  const int st = (int)(row >> 8), r = (int)(row & 255), nq = p.Tq >> 8;
+  const int tile = p.n_full + st, bh = tile / nq, qt = tile - bh * nq, b = bh / p.H, h = bh - b * p.H;
+  const float* r1 = p.ws + ((long long)(2 * st) * 256 + r) * 68;
+  const float* r2 = r1 + 256 * 68;
+  const float m1 = r1[64], l1 = r1[65], m2 = r2[64], l2 = r2[65];
+  const float m = fmaxf(m1, m2);
+  const float w1 = __builtin_amdgcn_exp2f(m1 - m), w2 = __builtin_amdgcn_exp2f(m2 - m);
+  const float inv = 1.f / (w1 * l1 + w2 * l2);
+  const float4 a0 = *reinterpret_cast<const float4*>(r1 + c8 * 8), a1 = *reinterpret_cast<const float4*>(r1 + c8 * 8 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(r2 + c8 * 8), b1 = *reinterpret_cast<const float4*>(r2 + c8 * 8 + 4);
+  const float s1 = w1 * inv, s2 = w2 * inv;
+  uint4 o;
+  o.x = Act<F16>::pack2(a0.x * s1 + b0.x * s2, a0.y * s1 + b0.y * s2);
+  o.y = Act<F16>::pack2(a0.z * s1 + b0.z * s2, a0.w * s1 + b0.w * s2);
+  o.z = Act<F16>::pack2(a1.x * s1 + b1.x * s2, a1.y * s1 + b1.y * s2);
+  o.w = Act<F16>::pack2(a1.z * s1 + b1.z * s2, a1.w * s1 + b1.w * s2);
+  *reinterpret_cast<uint4*>(p.o + b * p.bs_o + (long long)(qt * 256 + r) * p.ldo + h * 64 + c8 * 8) = o;
 }
 
 }  // namespace
@@ -158,10 +195,24 @@ __global__ __launch_bounds__(512) void attn_pp64_kernel(const AttnP p) {
 #define UR_ATTN_PP_LAUNCH ur_attn_pp_launch_bf16
 #endif
 
-int UR_ATTN_PP_LAUNCH(const void* pp, hipStream_t s) {
-  const AttnP& p = *static_cast<const AttnP*>(pp);
+// Workgroups per launch and how many of the trailing query tiles are split in two key halves.  One workgroup per CU: a grid of
+// n = whole rounds of 256 + r with 0 < r <= 128 leaves half of the chip idle for a whole tile time (B = 8, 5 heads, T = 4096:
+// 640 = 2.5 rounds); splitting the keys of those r tiles gives 2r <= 256 half-length workgroups that fill the last round.
+static void pp_plan(const AttnP& p, size_t ws_bytes, int& n_full, int& n_split) {
+  const long long n = (long long)(p.Tq / 256) * p.B * p.H, full = n / 256 * 256, r = n - full;
+  static const bool nosplit = getenv("UR_ATTN_NOSPLIT") && atoi(getenv("UR_ATTN_NOSPLIT")) != 0;
+  const bool split = !nosplit && p.ws && full >= 256 && r > 0 && r <= 128 && p.Tk % 512 == 0 && ws_bytes >= (size_t)r * 2 * 256 * 68 * 4;
+  n_split = split ? (int)r : 0;
+  n_full = (int)(n - n_split);
+}
+
+int UR_ATTN_PP_LAUNCH(const void* pp, size_t ws_bytes, hipStream_t s) {
+  AttnP p = *static_cast<const AttnP*>(pp);
+  int n_split;
+  pp_plan(p, ws_bytes, p.n_full, n_split);
+
   constexpr bool F16 = UR_TU_F16 != 0;
-  dim3 grid(p.Tq / 256, p.B * p.H), block(512);
+  dim3 grid(p.n_full + 2 * n_split), block(512);
   // UR_ATTN_PP_LDS (bytes, >= 32768): a larger request keeps further workgroups off the CU (occupancy experiments)
   static const int lds_env = getenv("UR_ATTN_PP_LDS") ? atoi(getenv("UR_ATTN_PP_LDS")) : 0;
   const int lds = lds_env > 4 * 16384 ? lds_env : 4 * 16384;
@@ -169,5 +220,6 @@ int UR_ATTN_PP_LAUNCH(const void* pp, hipStream_t s) {
   if (lds > 65536 && attr_once.first())
     hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_pp64_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((attn_pp64_kernel<F16>), grid, block, lds, s, p);
+  if (n_split) hipLaunchKernelGGL((attn_pp_combine_kernel<F16>), dim3(n_split * 8), dim3(256), 0, s, p, n_split);
   return ur::check_launch("ur_attention_fwd (ping-pong)");
 }

@@ -395,8 +395,10 @@ def attention(q, k, vt, heads: int, head_dim: int, tq: int, tk: int, scale: floa
     if not (q.dtype == k.dtype == vt.dtype) or q.dtype not in (BF16, F16):
         raise ValueError(f"attention: q, k, v^T must share one 16-bit type, got {q.dtype}, {k.dtype}, {vt.dtype}")
     out = torch.empty((batch, tq, c), dtype=q.dtype, device=q.device) if out is None else out
-    check(lib.ur_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, tq, tk, head_dim,
-                               ldq, ldk, vt.shape[-1], c, bs_q, bs_k, bs_vt, tq * c, scale, _dt(q), _stream()))
+    nws = lib.ur_attention_workspace_bytes(batch, heads, tq, tk, head_dim)       # key-split last round of the d = 64 kernel (0: none)
+    ws = torch.empty(nws, dtype=torch.uint8, device=q.device) if nws else None
+    check(lib.ur_attention_fwd_ws(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), batch, heads, tq, tk, head_dim,
+                                  ldq, ldk, vt.shape[-1], c, bs_q, bs_k, bs_vt, tq * c, scale, _ptr(ws), nws, _dt(q), _stream()))
     return out
 
 
