@@ -83,6 +83,8 @@ PK_ADD = SUM_MODE == "pk"
 # 143.0 us; the softmax phase is bound by the 32 v_exp_f32 at ~10 cycles each, not by its instruction count) and it needs an
 # s_nop between the pack and the MFMA that reads it (VALU write -> MFMA source: a real hazard, 16 red tests without it). Off.
 LATE_CVT = int(os.environ.get("ATTN_LATE_CVT", "0"))
+OUT_WT = int(os.environ.get("ATTN_OUT_WT", "0"))         # write-through stores of the output rows: +2.3 ms per forward (plain: the TAIL
+                                                         # chain re-reads them at once; common.h store16_wt has the A/B table)
 TILE = 8192
 STAGE = 16384
 SUM_MAX = 0x46800000      # 2^14
@@ -456,7 +458,7 @@ def program():
     for f in range(2):
         for g in range(4):
             d = S + 2 * (4 * f + g)
-            p(f"global_store_dwordx2 {OP['optr']}, {v(d, 2)}, off offset:{(f * 32 + 8 * g) * 2}")
+            p(f"global_store_dwordx2 {OP['optr']}, {v(d, 2)}, off offset:{(f * 32 + 8 * g) * 2}" + (" sc1" if OUT_WT else ""))
     p.label("end")
     if DBG:          # lanes 0..31 overwrite the first 24 bytes of their output row with the wave's timers
         p("s_waitcnt vmcnt(0)")

@@ -81,6 +81,33 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma16(const uint4& a, con
   } while (0)
 #define UR_REQUIRE_DT(dtype) UR_REQUIRE((dtype) == UR_DT_BF16 || (dtype) == UR_DT_F16, "dtype must be UR_DT_BF16 or UR_DT_F16")
 
+// 16 / 8-byte WRITE-THROUGH stores (sc1): the bytes leave the XCD's L2 while the kernel runs instead of in the write-back at its
+// end, and the line is dropped from that L2.  Site by site, same-box A/B of the whole forward (tools/ab_env.sh, ms per batch):
+//   conv / GEMM staged epilogue (tile_copy)          285.5 -> 283.6   kept
+//   GroupNorm apply output + split-K reduce (GN) out  281.7 -> 271.4   kept  (their consumers are halo convs on other CUs)
+//   split-K partial planes                            +6..8            plain (the reduce pass re-reads them from L2 at once)
+//   chain kernels' outputs (h0, q, k, v^T, y)         +3.5             plain
+//   direct epilogue, row reduce, elementwise, d=128 attention   +1.4   plain
+//   `nt` instead of sc1 on the conv epilogue: no change.
+typedef uint32_t ur_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ur_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16_wt(void* p, const uint4& v) {
+#ifdef UR_NO_WT_STORES
+  *reinterpret_cast<uint4*>(p) = v;
+#else
+  // (s_nop: a store of more than 8 bytes reads its data registers up to 2 wait states after issue, and hipcc's hazard
+  //  recogniser does not see into the asm - without it the next VALU result can land in them first)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(ur_u32x4, v)) : "memory");
+#endif
+}
+__device__ __forceinline__ void store8_wt(void* p, const uint2& v) {
+#ifdef UR_NO_WT_STORES
+  *reinterpret_cast<uint2*>(p) = v;
+#else
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(__builtin_bit_cast(ur_u32x2, v)) : "memory");
+#endif
+}
+
 // ------------------------------------------------------------------------------------------ math
 // SiLU with the hardware reciprocal (1 ulp) instead of an IEEE division (~10 instructions)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }

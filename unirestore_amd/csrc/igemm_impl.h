@@ -136,7 +136,9 @@ __device__ __forceinline__ void tile_copy(const ConvK& p, uint16_t* g, long long
     for (int u = 0; u < U; ++u) {
       if (!ok[u]) continue;
       if (LOAD) { lp[u][0] = make_uint2(v[u].x, v[u].y); lp[u][1] = make_uint2(v[u].z, v[u].w); }
-      else *reinterpret_cast<uint4*>(gp[u]) = v[u];
+      else {
+store16_wt(gp[u], v[u]);      // write-through for 3x3 and 1x1 launches alike (3x3 only: +3.7 ms, 1x1 only: +0.9 ms; common.h)
+      }
     }
   }
 }
@@ -413,7 +415,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
         for (int rg = 0; rg < 4; ++rg) {
           int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
           if (m < p.M && co < p.Cout)
-            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =
+            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =          // (plain stores: write-through here cost 6-8 ms)
                 make_float4(acc[a][b][rg * 4], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
         }
       }
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const ConvK p) {
       v[i][0] += Act<F16>::lo(rv[i].x); v[i][1] += Act<F16>::hi(rv[i].x);
       v[i][2] += Act<F16>::lo(rv[i].y); v[i][3] += Act<F16>::hi(rv[i].y);
       const uint2 o = make_uint2(Act<F16>::pack2(v[i][0], v[i][1]), Act<F16>::pack2(v[i][2], v[i][3]));
-      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.ldy + co) = o;
+      store8_wt(reinterpret_cast<uint16_t*>(p.y) + (long long)m * p.ldy + co, o);
       const float a[4] = {Act<F16>::lo(o.x), Act<F16>::hi(o.x), Act<F16>::lo(o.y), Act<F16>::hi(o.y)};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { sm[e] += a[e]; sq[e] += a[e] * a[e]; }

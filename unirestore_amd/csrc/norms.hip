@@ -148,7 +148,7 @@ __device__ __forceinline__ void gn_apply_body(const uint16_t* __restrict__ x, ui
         float o = f[e] * a[e] + b[e];
         f[e] = silu ? silu_f(o) : o;
       }
-      *reinterpret_cast<uint4*>(yo + (long long)pp * C_total) = pack8t<F16>(f);
+      store16_wt(yo + (long long)pp * C_total, pack8t<F16>(f));
     }
   }
 }
