@@ -82,12 +82,13 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma16(const uint4& a, con
 #define UR_REQUIRE_DT(dtype) UR_REQUIRE((dtype) == UR_DT_BF16 || (dtype) == UR_DT_F16, "dtype must be UR_DT_BF16 or UR_DT_F16")
 
 // 16 / 8-byte WRITE-THROUGH stores (sc1): the bytes leave the XCD's L2 while the kernel runs instead of in the write-back at its
-// end, and the line is dropped from that L2.  Site by site, same-box A/B of the whole forward (tools/ab_env.sh, ms per batch):
-//   conv / GEMM staged epilogue (tile_copy)          285.5 -> 283.6   kept
-//   GroupNorm apply output + split-K reduce (GN) out  281.7 -> 271.4   kept  (their consumers are halo convs on other CUs)
-//   split-K partial planes                            +6..8            plain (the reduce pass re-reads them from L2 at once)
-//   chain kernels' outputs (h0, q, k, v^T, y)         +3.5             plain
-//   direct epilogue, row reduce, elementwise, d=128 attention   +1.4   plain
+// end, and the line is dropped from that L2.  Site by site, same-box A/B of the whole forward (tools/ab_env.sh, ms per batch,
+// every figure re-measured on correct data - a first pass ran on NaNs, see the s_nop below, and NaNs run 10 ms faster):
+//   conv / GEMM staged epilogue (tile_copy) + GroupNorm apply output + split-K reduce (GN) output   281.8 -> 279.4   kept
+//       (their consumers are halo convs / GEMMs on other CUs; staged epilogue for 3x3 launches only +3.7, for 1x1 only +0.9)
+//   split-K partial planes                   273.8 -> 280.4   plain (the reduce pass re-reads them from L2 at once)
+//   chain kernels' outputs (h0, q, k, y)     273.8 -> 275.7   plain
+//   ping-pong attention output rows          273.8 -> 275.1   plain (the TAIL chain re-reads them at once)
 //   `nt` instead of sc1 on the conv epilogue: no change.
 typedef uint32_t ur_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t ur_u32x2 __attribute__((ext_vector_type(2)));

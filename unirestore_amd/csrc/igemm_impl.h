@@ -415,8 +415,13 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
         for (int rg = 0; rg < 4; ++rg) {
           int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
           if (m < p.M && co < p.Cout)
-            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =          // (plain stores: write-through here cost 6-8 ms)
+#ifdef UR_WT_PLANES         // A/B: write-through stores of the split-K partial planes
+            store16_wt(ws + (long long)m * p.Cout + co, make_uint4(__float_as_uint(acc[a][b][rg * 4]), __float_as_uint(acc[a][b][rg * 4 + 1]),
+                                                                  __float_as_uint(acc[a][b][rg * 4 + 2]), __float_as_uint(acc[a][b][rg * 4 + 3])));
+#else
+            *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =
                 make_float4(acc[a][b][rg * 4], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
+#endif
         }
       }
     return;

@@ -371,11 +371,16 @@ __device__ __forceinline__ void load_frags(const uint16_t* __restrict__ base, lo
 #pragma unroll
   for (int s = 0; s < 20; ++s) x[s] = *reinterpret_cast<const typename Frag<F16>::type*>(xp + 16 * s);
 }
+#ifdef UR_WT_CHAIN          // A/B: write-through stores of the chains' outputs (common.h store16_wt)
+#define TC_STORE16(ptr, val) store16_wt(ptr, __builtin_bit_cast(uint4, val))
+#else
+#define TC_STORE16(ptr, val) (*reinterpret_cast<uint4*>(ptr) = __builtin_bit_cast(uint4, val))
+#endif
 template <bool F16>
 __device__ __forceinline__ void store_frags(uint16_t* __restrict__ base, long long tok, int ld, int h, const typename Frag<F16>::type (&x)[20]) {
   uint16_t* xp = base + tok * ld + 8 * h;
 #pragma unroll
-  for (int s = 0; s < 20; ++s) *reinterpret_cast<typename Frag<F16>::type*>(xp + 16 * s) = x[s];
+  for (int s = 0; s < 20; ++s) TC_STORE16(xp + 16 * s, x[s]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -452,8 +457,8 @@ __device__ __forceinline__ void head_out(const TChain<F16>& tc, const f32x16 (&a
   frag_t o0, o1;
   tc.template ln_pack<F>(acc[F], slot, mean, rstd, o0, o1);
   if (part < 2) {                                                // q, k: straight out (two 16-byte stores per fragment)
-    *reinterpret_cast<frag_t*>(op + 32 * F) = o0;
-    *reinterpret_cast<frag_t*>(op + 32 * F + 16) = o1;
+    TC_STORE16(op + 32 * F, o0);
+    TC_STORE16(op + 32 * F + 16, o1);
   } else {                                                       // v: h0's fragments are dead now - keep v in their registers
     xb[2 * F] = o0;
     xb[2 * F + 1] = o1;
