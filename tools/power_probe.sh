@@ -6,6 +6,6 @@ echo "--- under load"
 ( $1 > /dev/null 2>&1 ) &
 PID=$!
 sleep ${2:-6}
-for i in 1 2 3 4 5 6; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "sclk|Socket Power|Average Graphics" | tr '\n' ' '; echo; sleep 0.5; done
+for i in 1 2 3 4 5 6; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "sclk|Socket Power|Average Graphics|Package Power" | tr '\n' ' '; echo; sleep 0.5; done
 wait $PID
 rocm-smi --showmaxpower 2>/dev/null | grep -i power | head -2
