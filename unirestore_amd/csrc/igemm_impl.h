@@ -415,13 +415,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[FN]
         for (int rg = 0; rg < 4; ++rg) {
           int co = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
           if (m < p.M && co < p.Cout)
-#ifdef UR_WT_PLANES         // A/B: write-through stores of the split-K partial planes
-            store16_wt(ws + (long long)m * p.Cout + co, make_uint4(__float_as_uint(acc[a][b][rg * 4]), __float_as_uint(acc[a][b][rg * 4 + 1]),
-                                                                  __float_as_uint(acc[a][b][rg * 4 + 2]), __float_as_uint(acc[a][b][rg * 4 + 3])));
-#else
+            // (plain stores: the reduce pass re-reads the planes from L2 at once - written through they cost 6.5 ms per forward)
             *reinterpret_cast<float4*>(ws + (long long)m * p.Cout + co) =
                 make_float4(acc[a][b][rg * 4], acc[a][b][rg * 4 + 1], acc[a][b][rg * 4 + 2], acc[a][b][rg * 4 + 3]);
-#endif
         }
       }
     return;
@@ -1152,23 +1148,8 @@ __device__ __forceinline__ void ig_lds_dma16(unsigned m0v, unsigned voff, const 
                "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
 }
 
-// the same with the non-temporal hint; A/B switches UR_DMA_NT_X (activations) / UR_DMA_NT_W (weights).  Measured on the whole
-// forward (same box): activations nt +5.2 ms, weights nt +12.4 ms - both operands are re-read through L2 (halo rows by the
-// neighbouring patches, weight tiles by every workgroup of the launch), so the default policy stays.
-__device__ __forceinline__ void ig_lds_dma16_nt(unsigned m0v, unsigned voff, const ig_u32x4& rs, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(rs),
-               "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
-}
-#ifdef UR_DMA_NT_X
-#define IG_DMA_X ig_lds_dma16_nt
-#else
-#define IG_DMA_X ig_lds_dma16
-#endif
-#ifdef UR_DMA_NT_W
-#define IG_DMA_W ig_lds_dma16_nt
-#else
-#define IG_DMA_W ig_lds_dma16
-#endif
+// (the `nt` hint on these loads measured +5.2 ms per forward on the activation pieces and +12.4 ms on the weight pieces: both
+// operands are re-read through L2 - halo rows by the neighbouring patches, weight tiles by every workgroup of the launch)
 
 // Pure-GEMM specialisation of the LDS-DMA ring (1x1 / Linear, single source): row base offsets are 32-bit element
 // offsets and nothing else is kept per row, which leaves room for 256 x 256 tiles (128 accumulator registers per wave).
@@ -1238,9 +1219,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
     const bool kval = kbase + chunk * 8 < p.Ktot;
     const unsigned so = (unsigned)kbase * 2u;
 #pragma unroll
-    for (int i = 0; i < XP; ++i) IG_DMA_X(xs + (i * RPP + wid_s * 8) * 128, kval ? xvo[i] : IG_OOB, rs_x, so);
+    for (int i = 0; i < XP; ++i) ig_lds_dma16(xs + (i * RPP + wid_s * 8) * 128, kval ? xvo[i] : IG_OOB, rs_x, so);
 #pragma unroll
-    for (int j = 0; j < WP; ++j) IG_DMA_W(wsm + (j * RPP + wid_s * 8) * 128, kval ? wvo[j] : IG_OOB, rs_w, so);
+    for (int j = 0; j < WP; ++j) ig_lds_dma16(wsm + (j * RPP + wid_s * 8) * 128, kval ? wvo[j] : IG_OOB, rs_w, so);
     kbase += 64;
   };
 #endif
@@ -1538,7 +1519,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
       const int qq = (wid_s + NW * i < WPIECES) ? wid_s + NW * i : wid_s;
-      IG_DMA_W(wring_lds + ring * WBYTES + qq * 1024, wvo[i], rs_w, (unsigned)(kt0 + kt) * 128u);
+      ig_lds_dma16(wring_lds + ring * WBYTES + qq * 1024, wvo[i], rs_w, (unsigned)(kt0 + kt) * 128u);
     }
   };
   auto issue_h = [&](int c, int t) {                                // halo piece (t*8 + wid) of chunk c
@@ -1547,8 +1528,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
     const unsigned ld2 = (unsigned)(second ? p.ldx2 : p.ldx) * 2u;
     const unsigned vo = hpix[t] >= 0 ? (unsigned)hpix[t] * ld2 + chunk * 16u : IG_OOB;
     const unsigned m0v = hbuf_lds + (c & 1) * HBYTES + (t * NW + wid_s) * 1024;
-    if (second) IG_DMA_X(m0v, vo, rs_x2, (unsigned)(cb - p.C1) * 2u);
-    else IG_DMA_X(m0v, vo, rs_x1, (unsigned)cb * 2u);
+    if (second) ig_lds_dma16(m0v, vo, rs_x2, (unsigned)(cb - p.C1) * 2u);
+    else ig_lds_dma16(m0v, vo, rs_x1, (unsigned)cb * 2u);
   };
 #endif
   // affine table of chunk c -> abuf[c & 1]: lanes 0-15 fetch a[64], lanes 16-31 b[64] (fp32), the rest a zero page.  Every
@@ -1816,7 +1797,7 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const
     auto dma_w = [&](int kt, int ring, int q0, int q1) {            // pieces [q0, q1) of weight tile kt (clamped) -> ring slot
       const unsigned so = (unsigned)(kt0 + min(kt, nk - 1)) * 128u;
 #pragma unroll
-      for (int q = q0; q < q1; ++q) IG_DMA_W(wring_lds + ring * WBYTES + q * 1024, wvo[q], rs_w, so);
+      for (int q = q0; q < q1; ++q) ig_lds_dma16(wring_lds + ring * WBYTES + q * 1024, wvo[q], rs_w, so);
     };
     auto dma_h = [&](int c, int h) {                                // patch pieces of half-tap h (0..15), chunk c (clamped) -> halo buffer c & 1
       const int cb = (c_begin + min(c, nchunk - 1)) * 64;           // first channel of the chunk: decides the source (C1 % 64 == 0)
@@ -1829,8 +1810,8 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const
         if (h < 16 && q < HNEED) {
           const unsigned vo = hpx[q] >= 0 ? (unsigned)hpx[q] * ld2 + ((q & 1) ? ck1 : ck0) : IG_OOB;
           const unsigned m0v = hbuf_lds + (c & 1) * HBYTES + q * 1024;
-          if (second) IG_DMA_X(m0v, vo, rs_x2, so);
-          else IG_DMA_X(m0v, vo, rs_x1, so);
+          if (second) ig_lds_dma16(m0v, vo, rs_x2, so);
+          else ig_lds_dma16(m0v, vo, rs_x1, so);
         }
       }
     };
@@ -1907,14 +1888,14 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const
 #pragma unroll
       for (int t = 0; t < 8; ++t)
         if (t * HTAP + wid_s < HNEED)
-          IG_DMA_X(hbuf_lds + (t * HTAP + wid_s) * 1024, hpix[t] >= 0 ? (unsigned)hpix[t] * ld2 + chunk * 16u : IG_OOB, rs_x, so);
+          ig_lds_dma16(hbuf_lds + (t * HTAP + wid_s) * 1024, hpix[t] >= 0 ? (unsigned)hpix[t] * ld2 + chunk * 16u : IG_OOB, rs_x, so);
     }
 #pragma unroll
     for (int j = 0; j < (WPIECES + NW - 1) / NW; ++j) {
       const int q = wid_s + NW * j;
       if (q < WPIECES) {
         const int row = n0 + q * 8 + lr;
-        IG_DMA_W(wring_lds + q * 1024, row < p.Cout ? (unsigned)row * (unsigned)p.ldw * 2u + chunk * 16u : IG_OOB, rs_w, (unsigned)kt0 * 128u);
+        ig_lds_dma16(wring_lds + q * 1024, row < p.Cout ? (unsigned)row * (unsigned)p.ldw * 2u + chunk * 16u : IG_OOB, rs_w, (unsigned)kt0 * 128u);
       }
     }
   }
@@ -2147,7 +2128,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
       const int qq = (wid_s + NW * i < WPIECES) ? wid_s + NW * i : wid_s;
-      IG_DMA_W(wring_lds + ring * WBYTES + qq * 1024, wvo[i], rs_w, (unsigned)(kt0 + kt) * 128u);
+      ig_lds_dma16(wring_lds + ring * WBYTES + qq * 1024, wvo[i], rs_w, (unsigned)(kt0 + kt) * 128u);
     }
   };
   auto issue_h = [&](int c, int t) {                                // c = chunk index local to this split
@@ -2156,8 +2137,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
     const unsigned ld2 = (unsigned)(second ? p.ldx2 : p.ldx) * 2u;
     const unsigned vo = hpix[t] >= 0 ? (unsigned)hpix[t] * ld2 + hchk[t] * 16u : IG_OOB;
     const unsigned m0v = hbuf_lds + (c & 1) * HBYTES + (t * NW + wid_s) * 1024;
-    if (second) IG_DMA_X(m0v, vo, rs_x2, (unsigned)(cb - p.C1) * 2u);
-    else IG_DMA_X(m0v, vo, rs_x1, (unsigned)cb * 2u);
+    if (second) ig_lds_dma16(m0v, vo, rs_x2, (unsigned)(cb - p.C1) * 2u);
+    else ig_lds_dma16(m0v, vo, rs_x1, (unsigned)cb * 2u);
   };
   auto issue_ab = [&](int c) {                            // affine table of chunk c -> abuf[c & 1] (see igemm_halo_kernel)
     const float* t = p.gn_ab + ((long long)img0 * 2 + (lane >> 4 & 1)) * p.Cin + (c_begin + c) * 64 + (lane & 15) * 4;

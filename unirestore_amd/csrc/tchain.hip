@@ -371,11 +371,8 @@ __device__ __forceinline__ void load_frags(const uint16_t* __restrict__ base, lo
 #pragma unroll
   for (int s = 0; s < 20; ++s) x[s] = *reinterpret_cast<const typename Frag<F16>::type*>(xp + 16 * s);
 }
-#ifdef UR_WT_CHAIN          // A/B: write-through stores of the chains' outputs (common.h store16_wt)
-#define TC_STORE16(ptr, val) store16_wt(ptr, __builtin_bit_cast(uint4, val))
-#else
+// (plain stores: the consumers re-read these rows from the same L2 at once - written through they cost 1.9 ms per forward, common.h)
 #define TC_STORE16(ptr, val) (*reinterpret_cast<uint4*>(ptr) = __builtin_bit_cast(uint4, val))
-#endif
 template <bool F16>
 __device__ __forceinline__ void store_frags(uint16_t* __restrict__ base, long long tok, int ld, int h, const typename Frag<F16>::type (&x)[20]) {
   uint16_t* xp = base + tok * ld + 8 * h;
