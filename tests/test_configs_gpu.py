@@ -56,9 +56,9 @@ def _oracle(o, img, task, noise, steps):
         return o(img, task, noise=noise, return_latents=True)
 
 
-def _check(o, m, img, task, steps, dtypes=("bf16", "fp16"), label=""):
+def _check(o, m, img, task, steps, dtypes=("bf16", "fp16"), label="", noise_seed=1234):
     from unirestore_amd.modules import resize_pad_plan
-    g = torch.Generator().manual_seed(1234)
+    g = torch.Generator().manual_seed(noise_seed)
     h, w, ph, pw = resize_pad_plan(*img.shape[-2:])
     shp = (img.shape[0], 4, (h + ph) // 8, (w + pw) // 8)
     noise = (torch.randn(shp, generator=g), torch.randn(shp, generator=g))
@@ -75,11 +75,15 @@ def _check(o, m, img, task, steps, dtypes=("bf16", "fp16"), label=""):
     m.set_dtype("bf16")
 
 
-def test_config1_sample_512_one_step(full):
-    """The sample bench.py reports as parity_vs_oracle: B=1, 512x512, 1 DDIM step (measured bf16 5.4e-3 / 4.0e-3 / 4.2e-3)."""
+@pytest.mark.parametrize("img_seed,noise_seed", [(42, 1234), (142, 2234), (242, 3234)])
+def test_config1_sample_512_one_step(full, img_seed, noise_seed):
+    """The sample bench.py reports as parity_vs_oracle (seeds 42 / 1234): B=1, 512x512, 1 DDIM step (measured bf16 5.4e-3 / 4.0e-3 /
+    4.2e-3, fp16 7.3e-4 / 8.1e-4 / 5.7e-4) - and two more images / noise draws, so that the fp16 margin against the hard 1e-3 is
+    not one sample's luck (round-4 run over the three draws: fp16 zt 8.09e-4 / 8.19e-4 / 7.94e-4, z0 7.3-7.5e-4, image 5.7e-4;
+    bf16 z0 5.38-5.45e-3, zt 3.98-4.06e-3, image 4.12-4.15e-3)."""
     o, m = full
-    img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(42))
-    _check(o, m, img, "ir", 1, label="configs[1] sample 512x512 / 1 step")
+    img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(img_seed))
+    _check(o, m, img, "ir", 1, label=f"configs[1] sample 512x512 / 1 step (seeds {img_seed}, {noise_seed})", noise_seed=noise_seed)
 
 
 def test_config0_256_four_steps(full):
