@@ -139,6 +139,8 @@ def qk_only(p, buf):
 
 
 NRING = 8       # fragment ring slots
+WAIT_EVERY = int(os.environ.get("ATTN_WAIT_EVERY", "1"))     # MFMAs per counted lgkmcnt wait (2 / 4: +-0 - as is dropping s_setprio: the launch
+                                                            # sits at the socket power cap, re-ordering instructions does not move it)
 NPRE = int(os.environ.get("ATTN_NPRE", "4"))        # fragment reads issued in front of the phase barrier (the rest of the ring behind it)
 DMA_AT = (3, 9)  # the phase's two DMA pieces go behind these MFMAs (issue slots in the shadow of the matrix pipe)
 
@@ -179,7 +181,8 @@ def mfma_phase(p, buf, with_qk, dma=None):
     pieces = list(dma[1]) if dma else []
     for i, (kind, j) in enumerate(seq):
         issued = min(n, NRING + i)
-        p(f"s_waitcnt lgkmcnt({issued - (i + 1)})")
+        if i % WAIT_EVERY == 0:          # one counted wait covers the fragments of the next WAIT_EVERY MFMAs (all issued already)
+            p(f"s_waitcnt lgkmcnt({issued - (min(i + WAIT_EVERY, n))})")
         slot = v(RING + 4 * (i % NRING), 4)
         if kind == "pv" and LATE_CVT and PV[j][0] >= 1 and PV[j][1] == 0:        # first use of P for this key step: pack it now
             for u in range(4):
