@@ -9,9 +9,10 @@ scheduled: 179.5 us on the 4 x 4096 x 4096 x 64 shape against 173.4 for the roun
 
 Structure (one workgroup = 8 waves = groups A (waves 0-3) and B (waves 4-7), one wave of each per SIMD, 32 queries per wave):
 
-    phase 2t     A: softmax(t), V^T fragment prefetch      B: P.V(t-1) + K.Q^T(t) interleaved, DMA of stage t+2
-    phase 2t+1   A: P.V(t) + K.Q^T(t+1), DMA of stage t+3  B: softmax(t), prefetch
-    s_barrier after every phase; a wave waits for its own older DMA pieces (vmcnt(2)) at the end of its softmax phase
+    between barrier #t and #t+1   A: P.V(t) + K.Q^T(t+1) interleaved + DMA of stage t+3, then softmax(t+1)
+                                  B: softmax(t), then P.V(t) + K.Q^T(t+1) + DMA of stage t+3
+    ONE s_barrier per tile (body_onebar has the LDS-safety argument); a wave waits for its own older DMA pieces (vmcnt(2)) at the
+    end of its softmax phase.  (The first version had a barrier after every phase: ATTN_ONEBAR=0, and the ATTN_DBG=1 timer build.)
 
   stage s = { V^T(s) | K(s+1) } (16 KiB) lives in LDS buffer s & 3; the loop is unrolled by four so every LDS offset is an
   immediate.  MFMA phase: P.V and K.Q^T alternate (four independent accumulator chains), fragments through an 8-slot register
@@ -367,9 +368,76 @@ def body(p, b):
     stamp(p, 3)
 
 
-def program():
+# One workgroup barrier per tile instead of two (body_onebar): 140.2 -> 134.3 us on the 4-head launch (1 023 TF/s), 198.0 -> 190.8
+# on the 5-head one.  ATTN_ONEBAR=0 / the ATTN_DBG=1 timer build keep the two-barrier program.
+ONEBAR = int(os.environ.get("ATTN_ONEBAR", "1")) and not DBG
+
+
+def body_onebar(p, b, grp):
+    """tile t = 4k + b with ONE barrier per tile.  Group A:  softmax(t) | barrier #t | MFMA(t)   (so between barriers it runs
+    MFMA(t) then softmax(t+1)); group B:  barrier #t | softmax(t) | MFMA(t)   (softmax first, then MFMA): the two waves of a SIMD
+    are complementary inside every interval and the softmax -> MFMA hand-over floats instead of waiting for the slower phase
+    twice per tile.  LDS safety needs no second barrier with four stage buffers: stage t+3 (issued inside MFMA(t)) overwrites stage
+    t-1, whose readers - MFMA(t-1) of both groups - finished before barrier #t; a wave waits for its own DMA pieces but the last
+    two at the end of every softmax phase, which puts every stage's pieces in LDS at least one barrier before its first reader.
+    (No fragment prefetch in front of a barrier here: group A would read a stage whose last pieces group B only waits for in
+    the same interval.)"""
+    tag = f"_{b}{'ab'[grp]}"
+    L = Prog.L
+    buf = (b + DIST) % NB
+    vc = "nodv" + tag if b >= NB - DIST else None
+    kc = "nodk" + tag if b >= NB - DIST - 1 else None
+    if grp == 1:
+        p("s_barrier")
+    softmax_phase(p, tag)
+    p(f"s_cmp_eq_u32 {OP['last']}, 1")
+    p(f"s_cbranch_scc1 {L('w0' + tag)}")
+    p("s_waitcnt vmcnt(2)")
+    p(f"s_branch {L('w1' + tag)}")
+    p.label("w0" + tag)
+    p("s_waitcnt vmcnt(0)")
+    p.label("w1" + tag)
+    if grp == 0:
+        p("s_barrier")
+    if b == NB - 1:
+        p(f"s_cmp_eq_u32 {OP['last']}, 1")
+        p(f"s_cbranch_scc1 {L('final')}")
+    p("s_setprio 1")
+    mfma_phase(p, b, True, dma=(buf, [("v", vc), ("k", kc)]))
+    p("s_setprio 0")
+
+
+def program_onebar():
+    global NPRE
+    assert DMA_IN == "m"
+    npre, NPRE = NPRE, 0
     p = Prog()
     L = Prog.L
+    program_init(p)
+    p("s_waitcnt vmcnt(0)")
+    p("s_barrier")
+    qk_only(p, NB - 1)
+    p(f"s_cmp_eq_u32 {OP['grp']}, 0")
+    p(f"s_cbranch_scc0 {L('loop_b')}")
+    for grp in (0, 1):
+        p.label("loop_" + "ab"[grp])
+        p(f"s_add_u32 {OP['last']}, {OP['t']}, {NB}")
+        p(f"s_cmp_ge_u32 {OP['last']}, {OP['nt']}")
+        p(f"s_cselect_b32 {OP['last']}, 1, 0")
+        for b in range(NB):
+            body_onebar(p, b, grp)
+        p(f"s_add_u32 {OP['t']}, {OP['t']}, {NB}")
+        p(f"s_branch {L('loop_' + 'ab'[grp])}")
+    p.label("final")
+    p("s_setprio 1")
+    mfma_phase(p, NB - 1, False)
+    p("s_setprio 0")
+    program_epilogue(p)
+    NPRE = npre
+    return p.lines
+
+
+def program_init(p):
     # ---- state
     for i in range(32):
         p(f"v_mov_b32 {v(O + i)}, 0")
@@ -395,6 +463,14 @@ def program():
         p("s_memrealtime vcc")
         p("s_waitcnt lgkmcnt(0)")
         p(f"s_mov_b32 {OP['rt0']}, vcc_lo")
+
+
+def program():
+    if ONEBAR:
+        return program_onebar()
+    p = Prog()
+    L = Prog.L
+    program_init(p)
     # ---- stages -1 (K(0), buffer 3), 0 .. DIST-1 were issued by the caller
     p("s_waitcnt vmcnt(0)")
     p("s_barrier")
@@ -427,6 +503,12 @@ def program():
     p(f"s_cbranch_scc0 {L('epi')}")
     p("s_barrier")
     p.label("epi")
+    program_epilogue(p)
+    return p.lines
+
+
+def program_epilogue(p):
+    L = Prog.L
     # ---- epilogue: l = l(lower half-wave) + l(upper), O / l -> 16 bit, lane owns query row, channels f*32 + 8g + 4hf + e
     p("s_nop 7")
     p(f"v_mov_b32 {v(PSUM)}, {v(LRUN)}")
