@@ -261,9 +261,13 @@ def exp_sum_pack(p, src_sub=None, hooks=None):
 def softmax_phase(p, tag, hooks=None):
     """fast path + slow path of one tile; ends with l += row sum.  hooks: instruction groups (the tile's DMA pieces) spliced into
     the fast path's exponential stream - every tile runs the fast path (tile 0 then always continues into the slow one)."""
+    if hooks is None:                  # nothing else rides in the fast path: tile 0 goes straight to the slow one
+        p(f"s_cmp_eq_u32 {OP['first']}, 1")
+        p(f"s_cbranch_scc1 {Prog.L('slow' + tag)}")
     exp_sum_pack(p, hooks=hooks)
-    p(f"s_cmp_eq_u32 {OP['first']}, 1")
-    p(f"s_cbranch_scc1 {Prog.L('slow' + tag)}")
+    if hooks is not None:
+        p(f"s_cmp_eq_u32 {OP['first']}, 1")
+        p(f"s_cbranch_scc1 {Prog.L('slow' + tag)}")
     p("s_nop 0")
     p(f"v_cmp_gt_f32_e32 vcc, {hex(SUM_MAX)}, {v(PSUM)}")
     p("s_cmp_eq_u64 vcc, exec")
