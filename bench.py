@@ -292,7 +292,7 @@ def main():
                               "share_of_forward": round(dom["ms"] / sum(v["ms"] for v in rep.values()), 3)}
         # HBM bytes of the most frequent launch of the conv family (conv3x3 320->320 @64x64, B=8), from separate rocprofv3 --pmc
         # passes (FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE), committed file; null for other families
-        for cand in ("r3_pmc_halo_conv.json", "r2_pmc_dominant.json", "r2_pmc_halo_conv.json"):
+        for cand in ("r4_pmc_halo_conv.json", "r3_pmc_halo_conv.json", "r2_pmc_dominant.json", "r2_pmc_halo_conv.json"):
             pmc = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
