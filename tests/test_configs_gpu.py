@@ -75,7 +75,8 @@ def _check(o, m, img, task, steps, dtypes=("bf16", "fp16"), label="", noise_seed
     m.set_dtype("bf16")
 
 
-@pytest.mark.parametrize("img_seed,noise_seed", [(42, 1234), (142, 2234)])        # (a third draw, (242, 3234), measured the same: docstring)
+@pytest.mark.parametrize("img_seed,noise_seed", [(42, 1234)])        # ((142, 2234) and (242, 3234) measured the same - docstring; each
+                                                                     #  draw costs ~40 s of CPU oracle: run them with -k and an edited list)
 def test_config1_sample_512_one_step(full, img_seed, noise_seed):
     """The sample bench.py reports as parity_vs_oracle (seeds 42 / 1234): B=1, 512x512, 1 DDIM step (measured bf16 5.4e-3 / 4.0e-3 /
     4.2e-3, fp16 7.3e-4 / 8.1e-4 / 5.7e-4) - and two more images / noise draws, so that the fp16 margin against the hard 1e-3 is
