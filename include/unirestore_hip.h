@@ -30,8 +30,10 @@ enum { UR_OK = 0, UR_E_INVALID = -1, UR_E_UNSUPPORTED = -2, UR_E_LAUNCH = -3, UR
 
 /* 16-bit storage / matrix-core operand type of activations and weights (accumulation, statistics, softmax, the DDIM state
  * and every tiny vector are fp32 in both).  UR_DT_BF16: precision: bf16-mixed of the reference (configs/val.yaml:12);
- * UR_DT_F16: IEEE half - same bytes and MFMA rate, 8x smaller rounding error per stored tensor, conversions saturate at
- * +-65504 (BASELINE.json configs[4], "fp16"). */
+ * UR_DT_F16: IEEE half - same bytes and MFMA rate, 8x smaller rounding error per stored tensor; a value beyond +-65504
+ * overflows to +-inf (IEEE; rounds 2-4 clamped) and turns into NaN in the next normalisation / softmax, so an fp16 range
+ * problem shows up in the output instead of as a silently clipped activation - fall back to UR_DT_BF16 for such weights
+ * (BASELINE.json configs[4], "fp16"). */
 enum { UR_DT_BF16 = 0, UR_DT_F16 = 1 };
 
 /* epilogue activations */
@@ -168,6 +170,11 @@ int ur_softmax_rows_f32(const float* s, void* p, long long rows, int cols, int l
  * vt:[B][H*D][ldvt] (V transposed: row = channel, column = key index), o:[B][Tq][ldo].  D in {64,128,512}
  * (512: the single 512-wide head of the VAE mid-block attention, split over keys for q.k and over channels for p.v
  *  inside one workgroup - no Tq x Tk matrix is materialised at any D).
+ * Scale convention for D == 64: the kernels work in the exp2 domain on scores multiplied by scale * log2(e).  Callers that
+ *   want full accuracy fold that factor into the QUERY PROJECTION's fp32 weights before their one rounding to 16 bits and pass
+ *   scale = ln 2 (scale * log2(e) == 1: q is used as it is) - unirestore_amd/modules/nn.py does.  Any other scale is honoured,
+ *   but the ping-pong kernel then multiplies the 16-bit q by the factor and rounds it to 16 bits a second time (bf16: one more
+ *   2^-9 relative rounding per q element; on scores of a few hundred that moves single softmax weights by ~5 %).
  * Replaces: F.scaled_dot_product_attention via diffusers AttnProcessor2_0 (UNet self/cross attention,
  *   Controller AttnDownBlock2D / UNetMidBlock2D attention) and the VAE mid-block AttentionBlock
  *   (/root/reference/src/modules/diffuie/autoencoder.py:37-45 calls it through vae.encoder/decoder.mid_block).

@@ -45,8 +45,10 @@ def test_no_kernel_uses_scratch_memory():
     # entry, reloaded between phases, never inside the FF loop) in scratch.  The allowance is PINNED to the measured bytes per
     # kernel and 16-bit type (hipcc 7.2): a compiler or source change that spills more - or any other kernel touching scratch at
     # all - fails here and has to be looked at (and, if it is the same kind of spill, re-pinned deliberately).
-    pinned = {("tchain_head_kernel", "Lb0E"): 20, ("tchain_head_kernel", "Lb1E"): 0,
-              ("tchain_tail_kernel", "Lb0E"): 52, ("tchain_tail_kernel", "Lb1E"): 68}
+    # (round 5: the fp16 pack lost its two clamps - IEEE overflow instead of saturation - which moved the fp16 kinds' allocation:
+    #  HEAD 0 -> 20 bytes, the bf16 kernel's figure, TAIL 68 -> 60; same lane-constant spills, re-pinned)
+    pinned = {("tchain_head_kernel", "Lb0E"): 20, ("tchain_head_kernel", "Lb1E"): 20,
+              ("tchain_tail_kernel", "Lb0E"): 52, ("tchain_tail_kernel", "Lb1E"): 60}
 
     def allowed(k):
         for (name, dt), v in pinned.items():
@@ -100,7 +102,7 @@ def test_ctypes_struct_layout_matches_the_header(tmp_path):
     assert int(out["sizeof"]) == ctypes.sizeof(capi.ConvDesc) and int(out["plan"]) == ctypes.sizeof(capi.ConvPlan)
 
 
-def test_generated_asm_blocks_are_current(tmp_path):
+def test_generated_asm_blocks_are_current(tmp_path, monkeypatch):
     """csrc/tchain_asm.inc, csrc/igemm_asm.inc, csrc/attention_pp_asm.inc and the timing-only variants tools/ab/*_abl{4,5}.inc are
     GENERATED (tools/gen_chain_asm.py, tools/gen_igemm_asm.py, tools/gen_attn_asm.py): the committed files must be exactly what
     the generators emit (with no ATTN_* environment switches set)."""
@@ -115,7 +117,7 @@ def test_generated_asm_blocks_are_current(tmp_path):
     import sys
     sys.path.insert(0, str(tools))
     for k in [k for k in os.environ if k.startswith("ATTN_")]:
-        del os.environ[k]
+        monkeypatch.delenv(k)                                # (restored when the test ends)
     argv, sys.argv = sys.argv, ["gen"]                       # (gen_attn_asm.py takes an optional output path)
     try:
         for mod in ("gen_chain_asm", "gen_igemm_asm", "gen_attn_asm"):

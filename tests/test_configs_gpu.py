@@ -64,6 +64,7 @@ def _check(o, m, img, task, steps, dtypes=("bf16", "fp16"), label="", noise_seed
     noise = (torch.randn(shp, generator=g), torch.randn(shp, generator=g))
     ref = _oracle(o, img, task, noise, steps)
     m.set_num_inference_steps(steps)
+    errs = {}
     for dt in dtypes:
         m.set_dtype(dt)
         got = m(img, task, noise=noise, return_latents=True)
@@ -72,19 +73,84 @@ def _check(o, m, img, task, steps, dtypes=("bf16", "fp16"), label="", noise_seed
         assert got[0].shape == img.shape and bool(torch.isfinite(got[0]).all())
         tz0, tzt, timg = TOL[dt]
         assert e[1] < tz0 and e[2] < tzt and e[0] < timg, (label, dt, e)
+        errs[dt] = e
     m.set_dtype("bf16")
+    return errs
 
 
-@pytest.mark.parametrize("img_seed,noise_seed", [(42, 1234)])        # ((142, 2234) and (242, 3234) measured the same - docstring; each
-                                                                     #  draw costs ~40 s of CPU oracle: run them with -k and an edited list)
+# fp16 regression bound on the tightest tensor (zt: measured 7.9-8.2e-4 over the three draws, rounds 4-5): the hard bar is 1e-3,
+# this is the early warning that the margin is being eaten
+FP16_ZT_REGRESSION = 9e-4
+
+
+@pytest.mark.parametrize("img_seed,noise_seed", [(42, 1234), (142, 2234), (242, 3234)])
 def test_config1_sample_512_one_step(full, img_seed, noise_seed):
     """The sample bench.py reports as parity_vs_oracle (seeds 42 / 1234): B=1, 512x512, 1 DDIM step (measured bf16 5.4e-3 / 4.0e-3 /
-    4.2e-3, fp16 7.3e-4 / 8.1e-4 / 5.7e-4) - and two more images / noise draws, so that the fp16 margin against the hard 1e-3 is
-    not one sample's luck (round-4 run over the three draws: fp16 zt 8.09e-4 / 8.19e-4 / 7.94e-4, z0 7.3-7.5e-4, image 5.7e-4;
-    bf16 z0 5.38-5.45e-3, zt 3.98-4.06e-3, image 4.12-4.15e-3)."""
+    4.2e-3, fp16 7.3e-4 / 8.1e-4 / 5.7e-4) - and two more images / noise draws IN the suite (round 5; ~40 s of CPU oracle each), so
+    that the fp16 margin against the hard 1e-3 is not one sample's luck (round-4 run over the three draws: fp16 zt 8.09e-4 /
+    8.19e-4 / 7.94e-4, z0 7.3-7.5e-4, image 5.7e-4; bf16 z0 5.38-5.45e-3, zt 3.98-4.06e-3, image 4.12-4.15e-3)."""
     o, m = full
     img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(img_seed))
-    _check(o, m, img, "ir", 1, label=f"configs[1] sample 512x512 / 1 step (seeds {img_seed}, {noise_seed})", noise_seed=noise_seed)
+    e = _check(o, m, img, "ir", 1, label=f"configs[1] sample 512x512 / 1 step (seeds {img_seed}, {noise_seed})", noise_seed=noise_seed)
+    assert e["fp16"][2] < FP16_ZT_REGRESSION, e["fp16"]
+
+
+def _scale_residual_writers(sd, frac, factor, seed):
+    """Heavy-tail stress: multiply `frac` of the output channels of every layer that WRITES the residual stream (ResnetBlock2D.conv2,
+    attention to_out, FeedForward.net.2, Transformer2DModel.proj_out) by `factor` - the shape real SD-2.x weights give their
+    'massive activation' channels.  Returns the edited copy."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".weight") and v.dim() >= 2 and v.shape[0] >= 64 and any(
+                t in k for t in (".conv2.weight", ".to_out.0.weight", ".ff.net.2.weight", ".proj_out.weight")):
+            idx = torch.randperm(v.shape[0], generator=g)[:max(1, int(round(v.shape[0] * frac)))].to(v.device)
+            v = v.clone()
+            v[idx] *= factor
+        out[k] = v
+    return out
+
+
+@pytest.mark.parametrize("factor", [100.0, 30000.0])
+def test_heavy_tailed_weights_fp16_is_loud_bf16_is_the_fallback(full, factor):
+    """1 % of the residual-stream writers' output channels scaled x100 / x30000 (full-size model, 512x512, 1 step) against the
+    oracle with the same edited weights.  What fp16 may do: overflow REFUSES loudly (FloatingPointError from the overflow -> inf ->
+    NaN -> finite check) - a clipped image is never handed back; a finite result is never worse than bf16's on the same sample
+    (the reference's own precision) and stays under 2e-3.  The north-star 1e-3 itself is a statement about well-scaled weights:
+    with x100 outlier channels the 16-bit rounding error of the big channels (relative 2^-11, absolute ~0.1 at |x| ~ 200) leaks
+    into the small ones through the next contraction - measured round 5: fp16 image 5.6e-4 / z0 7.3e-4 / zt 1.47e-3, bf16
+    4.6e-3 / 5.8e-3 / 3.3e-3.  bf16 (fp32 range) is the documented fall-back and stays inside its budget x 1.25."""
+    o, m = full
+    base = {k: v.clone() for k, v in m.state_dict().items()}
+    try:
+        sd = _scale_residual_writers(base, 0.01, factor, 7)
+        m.load_state_dict(sd)
+        o.load_state_dict({k: v.cpu() for k, v in sd.items()})
+        img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(52))
+        g = torch.Generator().manual_seed(5234)
+        noise = (torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g))
+        ref = _oracle(o, img, "ir", noise, 1)
+        assert bool(torch.isfinite(ref[0]).all())
+        m.set_num_inference_steps(1)
+        m.set_dtype("bf16")
+        got = m(img, "ir", noise=noise, return_latents=True)
+        eb = [rel_l2(a.cpu(), b) for a, b in zip(got, ref)]
+        m.set_dtype("fp16")
+        try:
+            got = m(img, "ir", noise=noise, return_latents=True)
+            ef = [rel_l2(a.cpu(), b) for a, b in zip(got, ref)]
+        except FloatingPointError as exc:
+            ef = None
+            assert "bf16" in str(exc)
+        print(f"heavy tail x{factor:g}: bf16 image/z0/zt {eb[0]:.2e} {eb[1]:.2e} {eb[2]:.2e}; fp16 " +
+              ("REFUSED (overflow -> FloatingPointError)" if ef is None else f"{ef[0]:.2e} {ef[1]:.2e} {ef[2]:.2e}"))
+        tz0, tzt, timg = TOL["bf16"]
+        assert eb[1] < tz0 and eb[2] < tzt and eb[0] < timg, eb
+        assert ef is None or (max(ef) < 2e-3 and all(f <= b for f, b in zip(ef, eb))), (ef, eb)
+    finally:
+        m.set_dtype("bf16")
+        m.load_state_dict(base)
+        o.load_state_dict({k: v.cpu() for k, v in base.items()})
 
 
 def test_config0_256_four_steps(full):

@@ -156,6 +156,30 @@ def test_controller_and_unet_step(M, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_controller_and_unet_per_sample_timesteps(M, dtype):
+    """Operator-level (B,) timesteps - the reference accepts them in Controller.forward / ControlledUNet.forward
+    (controller.py:193-194, base_model.py:211-216): image i is embedded with timesteps[i] (per-image bias rows)."""
+    o, p = _pair(M, 1, dtype=dtype)
+    from unirestore_amd import ops
+    ops.set_dtype(dtype)
+    g = torch.Generator().manual_seed(15)
+    z0, zt = torch.randn(3, 4, 16, 24, generator=g), torch.randn(3, 4, 16, 24, generator=g)
+    ts = torch.tensor([999, 249, 749])
+    with torch.no_grad():
+        oc = o.controller(z0, ts)
+        oe = o.base_model(zt, oc, ts)
+        oc1 = o.controller(z0[1:2], ts[1:2])                                 # image 1 alone at its own timestep
+    pc = p.controller(z0, ts)
+    e = {k: rel_l2(pc[k].cpu(), oc[k]) for k in oc}
+    e["eps"] = rel_l2(p.base_model(zt, oc, ts).cpu(), oe)
+    e["row1"] = max(rel_l2(pc[k][1:2].cpu(), oc1[k]) for k in oc1)
+    print(f"per-sample timesteps rel-L2 [{dtype}]:", e)
+    assert all(v < TOL[dtype]["ctrl"] for k, v in e.items() if k != "eps") and e["eps"] < TOL[dtype]["eps"], e
+    with pytest.raises(ValueError):
+        p.controller(z0, torch.tensor([999, 249]))                           # neither 1 nor B values
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_autoencoder_encode_decode(M, dtype):
     o, p = _pair(M, 2, dtype=dtype)
     from unirestore_amd import ops

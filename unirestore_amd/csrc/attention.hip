@@ -273,7 +273,7 @@ int UR_ATTN_LAUNCH(const void* pp, int D, hipStream_t s) {
   } else {
     constexpr int lds = 2 * (64 * 256 + 128 * 128);
     static ur::DeviceOnce attr_once;    // the attribute is per device
-    if (attr_once.first()) {
+    if (auto once_guard = attr_once.first()) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<128, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
     hipLaunchKernelGGL((attn_fwd_kernel<128, F16>), grid, block, lds, s, p);
@@ -282,15 +282,8 @@ int UR_ATTN_LAUNCH(const void* pp, int D, hipStream_t s) {
 }
 
 #if !UR_TU_F16
-// half-tile count the ping-pong launch would split (0: no workspace wanted) - one rule for the size query and the launch
-static long long pp_split_tiles(int B, int H, int Tq, int Tk, int D) {
-  if (D != 64 || Tq % 256 || Tk % 512) return 0;
-  const long long n = (long long)(Tq / 256) * B * H, r = n % 256;
-  return (n >= 512 && r > 0 && r <= 128) ? r : 0;
-}
-
 extern "C" size_t ur_attention_workspace_bytes(int B, int H, int Tq, int Tk, int D) {
-  return B > 0 && H > 0 && Tq > 0 && Tk > 0 ? (size_t)pp_split_tiles(B, H, Tq, Tk, D) * 2 * 256 * 68 * 4 : 0;
+  return B > 0 && H > 0 && Tq > 0 && Tk > 0 ? attn_pp_ws_bytes(attn_pp_split_tiles(B, H, Tq, Tk, D)) : 0;      // (attention_params.h: the one rule)
 }
 
 extern "C" int ur_attention_fwd_ws(const void* q, const void* k, const void* vt, void* o, int B, int H, int Tq, int Tk, int D,
@@ -318,9 +311,10 @@ extern "C" int ur_attention_fwd_ws(const void* q, const void* k, const void* vt,
   // 640 workgroups = 2.5 rounds: 203 us unsplit against 229 for the 128-query kernel below; 320 = 1.25 rounds unsplit: 42 against
   // 39 us.  UR_ATTN_NOPP=1 keeps the round-1 kernel everywhere (A/B, tests).
   static const bool nopp = getenv("UR_ATTN_NOPP") && atoi(getenv("UR_ATTN_NOPP")) != 0;
-  if (D == 64 && Tq % 256 == 0 && Tk % 256 == 0 && !nopp) {
+  if (!nopp && attn_pp_shape_ok(p, D)) {          // (anything else - ragged tiles, unaligned views - takes the kernel below, which has tails)
     const long long wgs = (long long)(Tq / 256) * B * H;
-    const long long r = ws && ws_bytes >= ur_attention_workspace_bytes(B, H, Tq, Tk, D) ? pp_split_tiles(B, H, Tq, Tk, D) : 0;
+    const long long rs = attn_pp_split_tiles(B, H, Tq, Tk, D);
+    const long long r = ws && ws_bytes >= attn_pp_ws_bytes(rs) ? rs : 0;
     const double rounds = r ? (double)(wgs - r) / 256 + 0.5 : (double)((wgs + 255) / 256);
     if (wgs <= 256 || wgs >= rounds * 256 * 0.75)
       return dtype == UR_DT_F16 ? ur_attn_pp_launch_f16(&p, ws_bytes, s) : ur_attn_pp_launch_bf16(&p, ws_bytes, s);

@@ -223,7 +223,7 @@ int UR_ATTN512_LAUNCH(const void* pp, hipStream_t s) {
   const AttnP& p = *static_cast<const AttnP*>(pp);
   constexpr bool F16 = UR_TU_F16 != 0;
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&attn512_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, A5_LDS);
   }
   dim3 grid((p.Tq + A5_BQ - 1) / A5_BQ, p.B * p.H), block(256);

@@ -199,15 +199,16 @@ __global__ __launch_bounds__(256) void attn_pp_combine_kernel(const AttnP p, int
 // n = whole rounds of 256 + r with 0 < r <= 128 leaves half of the chip idle for a whole tile time (B = 8, 5 heads, T = 4096:
 // 640 = 2.5 rounds); splitting the keys of those r tiles gives 2r <= 256 half-length workgroups that fill the last round.
 static void pp_plan(const AttnP& p, size_t ws_bytes, int& n_full, int& n_split) {
-  const long long n = (long long)(p.Tq / 256) * p.B * p.H, full = n / 256 * 256, r = n - full;
-  static const bool nosplit = getenv("UR_ATTN_NOSPLIT") && atoi(getenv("UR_ATTN_NOSPLIT")) != 0;
-  const bool split = !nosplit && p.ws && full >= 256 && r > 0 && r <= 128 && p.Tk % 512 == 0 && ws_bytes >= (size_t)r * 2 * 256 * 68 * 4;
-  n_split = split ? (int)r : 0;
+  const long long n = (long long)(p.Tq / 256) * p.B * p.H, r = attn_pp_split_tiles(p.B, p.H, p.Tq, p.Tk, 64);      // (attention_params.h)
+  n_split = (r && p.ws && ws_bytes >= attn_pp_ws_bytes(r)) ? (int)r : 0;
   n_full = (int)(n - n_split);
 }
 
 int UR_ATTN_PP_LAUNCH(const void* pp, size_t ws_bytes, hipStream_t s) {
   AttnP p = *static_cast<const AttnP*>(pp);
+  // the asm loop has no tails and its buffer descriptors no range check: refuse what the dispatcher should never send
+  if (!attn_pp_shape_ok(p, 64) || (p.ws && ((unsigned long long)p.ws & 15ull)))
+    return ur::fail(UR_E_INVALID, "ping-pong attention: needs Tq, Tk multiples of 256 and 16-byte aligned q / k / v^T rows");
   int n_split;
   pp_plan(p, ws_bytes, p.n_full, n_split);
 
@@ -217,7 +218,8 @@ int UR_ATTN_PP_LAUNCH(const void* pp, size_t ws_bytes, hipStream_t s) {
   static const int lds_env = getenv("UR_ATTN_PP_LDS") ? atoi(getenv("UR_ATTN_PP_LDS")) : 0;
   const int lds = lds_env > 4 * 16384 ? lds_env : 4 * 16384;
   static ur::DeviceOnce attr_once;
-  if (lds > 65536 && attr_once.first())
+  if (lds > 65536)
+  if (auto once_guard = attr_once.first())
     hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_pp64_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((attn_pp64_kernel<F16>), grid, block, lds, s, p);
   if (n_split) hipLaunchKernelGGL((attn_pp_combine_kernel<F16>), dim3(n_split * 8), dim3(256), 0, s, p, n_split);

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/unirestore_hip.h"
 
@@ -34,7 +36,7 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 
 // ------------------------------------------------------------------------------------------ 16-bit activation types
 // Every kernel that touches 16-bit activations / weights is a template on F16: false = bf16 (8-bit mantissa, fp32 range),
-// true = IEEE fp16 (11-bit mantissa: ~8x smaller rounding error per stored tensor, range +-65504 - conversions saturate).
+// true = IEEE fp16 (11-bit mantissa: ~8x smaller rounding error per stored tensor, range +-65504 - conversions overflow to inf).
 // Both feed v_mfma_f32_32x32x16_{bf16,f16} at the same rate with fp32 accumulation.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
@@ -49,8 +51,11 @@ template <> struct Act<true> {
   static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
   static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
   static __device__ __forceinline__ float one(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
-  static __device__ __forceinline__ uint32_t pack2(float a, float b) {     // round-to-nearest-even, saturating (no inf)
-    f32x2_t v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+  // round-to-nearest-even, IEEE overflow: |v| > 65504 becomes +-inf (round 5; rounds 2-4 clamped to +-65504).  A clipped
+  // activation is a silently wrong image; an inf reaches the next GroupNorm / softmax as NaN and the caller's finite check
+  // (DiffUIE.forward raises FloatingPointError in fp16) - overflow is loud, and the pack is one instruction like bf16's.
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    f32x2_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
   }
 };
@@ -167,15 +172,37 @@ void zero_async(void* ptr, size_t bytes, hipStream_t s);
 int gn_stats_parts(int N, int HW, int C);
 int gn_stats_launch(const void* x, float* part, int N, int HW, int C, int dtype, hipStream_t s);
 
-// `first()` is true once per DEVICE: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device attribute, and one process
-// may drive several GPUs.
+// Once-per-DEVICE section: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device attribute, and one process may drive
+// several GPUs from several host threads.  `if (auto once = x.first()) { ... }` runs the body in exactly one thread per device;
+// every other thread that asks meanwhile BLOCKS until that body has finished (the guard releases the lock at the end of the
+// if-statement), so nobody launches with > 64 KiB of dynamic LDS before the attribute is set.  Devices are keyed exactly (no
+// aliasing above 63: one bit vector word per 64 devices).
 struct DeviceOnce {
-  std::atomic<unsigned long long> mask{0};
-  bool first() {
+  std::mutex mu;
+  std::vector<unsigned long long> done;
+  struct Guard {
+    std::unique_lock<std::mutex> lk;
+    std::vector<unsigned long long>* done = nullptr;
+    int dev = 0;
+    bool run = false;
+    Guard() = default;
+    Guard(Guard&& o) noexcept : lk(std::move(o.lk)), done(o.done), dev(o.dev), run(o.run) { o.run = false; }
+    explicit operator bool() const { return run; }
+    ~Guard() {
+      if (run) (*done)[dev >> 6] |= 1ull << (dev & 63);        // still under the lock: waiters see the finished state
+    }
+  };
+  Guard first() {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    return !(mask.fetch_or(bit) & bit);
+    Guard g;
+    g.lk = std::unique_lock<std::mutex>(mu);
+    if ((size_t)(dev >> 6) >= done.size()) done.resize((dev >> 6) + 1, 0ull);
+    g.run = !(done[dev >> 6] >> (dev & 63) & 1ull);
+    g.done = &done;
+    g.dev = dev;
+    if (!g.run) g.lk.unlock();
+    return g;
   }
 };
 

@@ -60,6 +60,12 @@ static inline int g1_128x64(void* kp, hipStream_t s) { return static_cast<ConvK*
 int g1_64x64_bf16(void* kp, hipStream_t s);
 int g1_64x64_f16(void* kp, hipStream_t s);
 static inline int g1_64x64(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? g1_64x64_f16(kp, s) : g1_64x64_bf16(kp, s); }
+int g1_64x64_deep_bf16(void* kp, hipStream_t s);
+int g1_64x64_deep_f16(void* kp, hipStream_t s);
+static inline int g1_64x64_deep(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? g1_64x64_deep_f16(kp, s) : g1_64x64_deep_bf16(kp, s); }
+int g1_128x64_deep_bf16(void* kp, hipStream_t s);
+int g1_128x64_deep_f16(void* kp, hipStream_t s);
+static inline int g1_128x64_deep(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? g1_128x64_deep_f16(kp, s) : g1_128x64_deep_bf16(kp, s); }
 int halo_8x32_160_bf16(void* kp, hipStream_t s);
 int halo_8x32_160_f16(void* kp, hipStream_t s);
 static inline int halo_8x32_160(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? halo_8x32_160_f16(kp, s) : halo_8x32_160_bf16(kp, s); }
@@ -136,6 +142,13 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
     // (>= 128 such tiles run faster unsplit up to K = 3072 than split with a reduce pass: 512 x 1280 x 1280 11.3 vs 14.6 us,
     //  2048 x 1280 x 2560 29 vs 34 us - tools/ab_gemm_sweep.py)
     const long long blocks64 = (long long)((k.M + 63) / 64) * ((k.Cout + 63) / 64) * k.nbatch;
+    // (grids of <= 256 workgroups - the 8x8 level - are latency-bound per K tile: four ring stages, and K up to 2560 stays unsplit:
+    //  512 x 1280 x 1280 12.9 -> 9.1 us, x 2560 20.8 (split + reduce) -> 14.3 us; profiles/r5_wreg_ab.txt)
+    static const bool no_deep = getenv("UR_IGEMM_NODEEP") != nullptr;
+    if (!no_deep && blocks128 < 200 && g1 && blocks64 >= 128 && blocks64 <= 256 && k.nk >= 8 && k.nk <= 48) return urk::g1_64x64_deep(&k, s);
+    // long-K GEMMs of the 16x16 level: 128 x 64 tiles, three stages, unsplit (2048 x 1280 x 2560 25.9 -> 23.3 us, x 5120 49.1 -> 43.7 us)
+    if (!no_deep && g1 && blocks128 < 200 && k.nk > 24 && k.nk <= 96 && (long long)((k.M + 127) / 128) * ((k.Cout + 63) / 64) * k.nbatch >= 256)
+      return urk::g1_128x64_deep(&k, s);
     if (blocks128 < 200 && g1 && ((blocks64 >= 128 && k.nk <= 24) || (blocks64 >= 256 && k.nk <= 48))) return urk::g1_64x64(&k, s);
     if (blocks128 < 200 && k.nk <= 24) return g1 && nosplit(64, 64) ? urk::g1_64x64(&k, s) : urk::v1_64x64(&k, s);
     // 1 < tiles/CU < 2 at 128 x 128: halve the N tile so every CU gets the same work

@@ -20,6 +20,11 @@ int URK(g1_128x128)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(k
 int URK(g1_128x160)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 160, 4, 1, UR_NST_128x160, true>(k, s); }
 int URK(g1_128x64)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 64, 2, 2, UR_NST_128x64, true>(k, s); }
 int URK(g1_64x64)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<64, 64, 2, 2, UR_NST_64x64, true>(k, s); }
+// deeper rings where the round-5 sweep (profiles/r5_wreg_ab.txt) found them: 64 x 64 / 4 stages for grids of <= 256 workgroups (the 8x8
+// level: less than one workgroup per CU IS latency-bound: 512 x 1280 x 1280 12.9 -> 9.1 us), 128 x 64 / 3 stages unsplit for the long-K
+// 16x16-level GEMMs (2048 x 1280 x 2560 25.9 -> 23.3 us, x 5120 49.1 -> 43.7 us against split-K + reduce)
+int URK(g1_64x64_deep)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<64, 64, 2, 2, 4, true>(k, s); }
+int URK(g1_128x64_deep)(void* kp, hipStream_t s) { ConvK& k = *static_cast<ConvK*>(kp); return launch_gemm<128, 64, 2, 2, 3, true>(k, s); }
 #ifdef UR_AB_VARIANTS      // tools/ab_variants.sh: every tile shape x ring depth behind one entry point, chosen by UR_AB_ID at run time
 int URK(g1_ab)(void* kp, hipStream_t s, int id) {
   ConvK& k = *static_cast<ConvK*>(kp);

@@ -932,7 +932,7 @@ int launch_cfg(ConvK& k, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static_assert(epi_lds_bytes<BM, BN, 256>() <= lds, "epilogue staging must fit the K ring");
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, false, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, true, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
     for (int s = 0; s < NST - 1; ++s)
       if (issued < ntile) { issue_tile(s); ++issued; }
     // wait for tile 0
-    if (issued >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD * (NST - 2)) : "memory");
+    if (issued == NST - 1 && NST >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD * (NST - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int cs = 0, is = (NST - 1) % NST;
@@ -1242,7 +1242,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (issued < ntile) { issue_tile(s); ++issued; }
-  if (NST >= 3 && issued >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
+  // (tile 0 has landed when at most the NST - 2 tiles behind it are outstanding - only if all NST - 1 were issued: a K shorter
+  //  than the ring drains it instead)
+  if (NST >= 3 && issued == NST - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLD * (NST >= 3 ? NST - 2 : 0)) : "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int cs = 0, is = (NST - 1) % NST;
@@ -1299,7 +1301,7 @@ int launch_gemm(ConvK& k, hipStream_t s) {
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   UR_F16_SWITCH(k, hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC, F16>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k));
@@ -1325,7 +1327,7 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
   constexpr int lds_loop = NST * (BM + BN) * 128, lds_epi = epi_lds_bytes<BM, BN, WM * WN * 64>();
   constexpr int lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, WM, WN, NST, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
@@ -2028,7 +2030,7 @@ int launch_halo(ConvK& k, hipStream_t s) {
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
   k.patch_tw = 32;
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_ws_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -2282,7 +2284,7 @@ int launch_halo_img(ConvK& k, hipStream_t s) {
   set_gn_plan(k, (k.OHW % BM) == 0, k.OHW / BM);
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }

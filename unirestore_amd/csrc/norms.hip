@@ -69,6 +69,10 @@ __global__ void gn_finalize_kernel(const float* __restrict__ p1, int P1, int C1,
   __shared__ double red[2][256];
   const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x, NT = blockDim.x;
   const int C = C1 + C2, cpg = C / G, c_lo = g * cpg, Pmax = max(P1, P2);
+  // gamma / beta of the lane's first channel: issued next to the plane loads (behind the reduction they were a second,
+  // serialised memory latency in a kernel that is nothing but a latency chain)
+  float ga0 = 1.f, be0 = 0.f;
+  if (ab && t < cpg) { ga0 = gamma ? gamma[c_lo + t] : 1.f; be0 = beta ? beta[c_lo + t] : 0.f; }
   double s = 0.0, q = 0.0;
   for (int idx = t; idx < cpg * Pmax; idx += NT) {
     const int p = idx / cpg, c = c_lo + (idx - p * cpg);
@@ -99,9 +103,9 @@ __global__ void gn_finalize_kernel(const float* __restrict__ p1, int P1, int C1,
   if (ab)
     for (int i = t; i < cpg; i += NT) {
       const int c = c_lo + i;
-      const float a = rstd * (gamma ? gamma[c] : 1.f);
+      const float a = rstd * (i == t ? ga0 : (gamma ? gamma[c] : 1.f));
       ab[((long long)n * 2) * C + c] = a;
-      ab[((long long)n * 2 + 1) * C + c] = (beta ? beta[c] : 0.f) - (float)mean * a;
+      ab[((long long)n * 2 + 1) * C + c] = (i == t ? be0 : (beta ? beta[c] : 0.f)) - (float)mean * a;
     }
 }
 

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void tchain_mlp_kernel(const MlpP p) {
 template <bool F16>
 int launch_mlp(const MlpP& p, hipStream_t s) {
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&tchain_mlp_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
   }
   hipLaunchKernelGGL((tchain_mlp_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256, 1) void tchain_tail_kernel(const TailP p) {
 template <bool F16>
 int launch_head(const HeadP& p, hipStream_t s) {
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&tchain_head_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
   }
   hipLaunchKernelGGL((tchain_head_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);
@@ -763,7 +763,7 @@ int launch_head(const HeadP& p, hipStream_t s) {
 template <bool F16>
 int launch_csce(const CsceP& p, hipStream_t s) {
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&tchain_csce_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
   }
   hipLaunchKernelGGL((tchain_csce_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);
@@ -772,7 +772,7 @@ int launch_csce(const CsceP& p, hipStream_t s) {
 template <bool F16>
 int launch_tail(const TailP& p, hipStream_t s) {
   static ur::DeviceOnce attr_once;      // the attribute is per device
-  if (attr_once.first()) {
+  if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&tchain_tail_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
   }
   hipLaunchKernelGGL((tchain_tail_kernel<F16>), dim3(p.T / TC_TOK), dim3(256), TC_LDS, s, p);

@@ -40,6 +40,15 @@ def _use_dtype(module):
         ops.set_dtype(dt)
 
 
+def _per_sample_timesteps(timesteps, batch):
+    """Reference operator contract (controller.py:193-194, base_model.py:211-216): `timesteps` is a scalar / (1,) tensor shared by
+    the batch, or a (B,) tensor with one timestep per sample.  Returns [t] or the B per-sample values (all-equal collapses to [t])."""
+    ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
+    if len(ts) != 1 and len(ts) != batch:
+        raise ValueError(f"timesteps must hold 1 or {batch} values, got {len(ts)}")
+    return ts[:1] if len(set(ts)) == 1 else ts
+
+
 def _resnets(module):
     return [m for m in module.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
 
@@ -115,11 +124,11 @@ class Controller(nn.Module):
     def forward(self, x, timesteps, encoder_hidden_states=None):
         """Reference signature: x (B,4,h,w) fp32 NCHW, timesteps (1,) or (B,) -> {width: (B,256,h',w') fp32}."""
         _use_dtype(self)
-        ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
-        if len(set(ts)) != 1:
-            raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
-        self.set_timesteps(ts[:1])
-        out = self.run(self.stem(ops.nchw_to_nhwc(x.to(DEV))), 0)
+        ts = _per_sample_timesteps(timesteps, x.shape[0])
+        self.set_timesteps(ts)
+        # one table row per distinct request: a (1,) tensor is row 0 for every image; a (B,) tensor gives image i row i
+        # (controller.py:193-194 broadcasts the same way) - the step-major "all" form with one image per row
+        out = self.run(self.stem(ops.nchw_to_nhwc(x.to(DEV))), 0 if len(ts) == 1 else "all")
         return {k: ops.nhwc_to_nchw(v) for k, v in out.items()}
 
 
@@ -201,12 +210,10 @@ class ControlledUNet(nn.Module):
     def forward(self, sample, control, timesteps):
         """Reference signature (base_model.py:211-245): NCHW fp32 in, eps NCHW fp32 out."""
         _use_dtype(self)
-        ts = [int(t) for t in torch.as_tensor(timesteps).reshape(-1).tolist()]
-        if len(set(ts)) != 1:
-            raise NotImplementedError("per-sample timesteps: use DiffUIE.predict_z0")
-        self.set_timesteps(ts[:1])
+        ts = _per_sample_timesteps(timesteps, sample.shape[0])
+        self.set_timesteps(ts)
         ctl = {k: ops.nchw_to_nhwc(v.to(DEV)) for k, v in control.items()}
-        eps = self.run(ops.nchw_to_nhwc(sample.to(DEV)), ctl, 0)
+        eps = self.run(ops.nchw_to_nhwc(sample.to(DEV)), ctl, 0 if len(ts) == 1 else "all")     # (B,) timesteps: image i = bias row i
         return ops.nhwc_to_nchw(eps, c=self.unet.conv_out.out_channels)
 
 
@@ -322,6 +329,7 @@ class DiffUIE(nn.Module):
         self.tedit = tedit if tedit else None
         self.ae = SkipConnectedAutoEncoder(AutoencoderKL(**(vae_cfg or {})), self.fr_type, self.tedit, fr_depths)
         self.use_graph = use_graph
+        self.check_fp16_overflow = True        # fp16 only: one isfinite reduction over the restored images per forward (+ a sync)
         self.batch_controller = os.environ.get("UR_BATCH_CONTROLLER", "1") == "1"
         self._graphs = {}
         if self.control_type:
@@ -468,6 +476,11 @@ class DiffUIE(nn.Module):
             preds, z0, zt = self._graph_forward(images, task, n_vae, n_t, plan, quantize)
         else:
             preds, z0, zt = self._forward_device(images, task, n_vae, n_t, plan, quantize)
+        if self.dtype == torch.float16 and self.check_fp16_overflow and not bool(torch.isfinite(preds).all()):
+            # fp16 conversions overflow to inf (csrc/common.h Act<true>::pack2); an inf becomes NaN in the next GroupNorm /
+            # softmax and reaches the image.  Heavy-tailed activations (real SD-2.x weights can produce them) need bf16.
+            raise FloatingPointError("fp16 activation overflow (|x| > 65504) somewhere in the forward: the restored image is not "
+                                     "finite.  Run this model with dtype='bf16' (DiffUIE.set_dtype('bf16') / trainer.precision: bf16-mixed)")
         if return_latents:
             return preds, ops.nhwc_to_nchw(z0, c=lat), ops.nhwc_to_nchw(zt, c=lat)
         return preds
