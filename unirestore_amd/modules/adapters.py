@@ -4,6 +4,8 @@ Same constructor signatures, parameter names and forward semantics as the refere
 (scedit.py:24-38, nafnet_arch.py:28-131, cfrm.py:12-54, taskeditor.py:10-108); `forward` takes/returns NCHW fp32
 tensors like the reference operators, `run` is the NHWC bf16 fast path the model graph uses.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -11,6 +13,11 @@ from .. import chain, ops
 from ..ops import UR_ACT_GATE, UR_ACT_GELU, UR_ACT_NONE, UR_ACT_RELU, UR_ACT_TANH
 from . import nn as _nn
 from .nn import DEV, Conv2d, LayerNorm, Linear, GroupNorm
+
+
+# LayerNorm2d of the NAFBlocks folded into the consuming 1x1 convs (the mechanism of the transformer blocks' LayerNorms): 25 of the
+# 28 LayerNorm passes of a forward disappear.  UR_FUSE_LN2D=0: separate passes (A/B).
+FUSE_LN2D = os.environ.get("UR_FUSE_LN2D", "1") == "1"
 
 
 def _named(**mods):
@@ -121,15 +128,30 @@ class NAFBlock(nn.Module):
                                    self.sca["1"].bias.detach().float().to(DEV))
         return self.__dict__["dw"]
 
+    def _ln_folded(self, conv, norm, pair):
+        """1x1 conv of LayerNorm2d(x): LayerNorm over C folded into the GEMM (w' = W * gamma, b' = W.beta + b; the epilogue applies
+        rstd * (acc - mean * colsum) from the row sums the PRODUCER of x left) - no LayerNorm pass, no normalised tensor."""
+        key = ("cache", "ln", id(conv), pair, ops.act_dtype())
+        if key not in self.__dict__:
+            self.__dict__[key] = ops.pack_linear_ln(conv.weight.detach().float().flatten(1), conv.bias, norm.weight, norm.bias, norm.eps, DEV, pair=pair)
+        return self.__dict__[key]
+
     def run(self, inp):
         w9c, b2, wsca, bsca = self._dw()
-        x = ops.conv(self.norm1.run(inp), self.conv1.packed())
+        st = ops.ln_of(inp) if FUSE_LN2D else None
+        if st is not None:                        # the producer (previous NAFBlock / AdaNAFV2.pwconv) left per-pixel channel sums
+            x = ops.conv(inp, self._ln_folded(self.conv1, self.norm1, False), ln_stats=st)
+        else:
+            x = ops.conv(self.norm1.run(inp), self.conv1.packed())
         x = ops.dwconv3x3(x, w9c, b2, gate=True)                               # depthwise + SimpleGate
         s = ops.linear_f32(ops.avgpool(x), wsca, bsca)                         # simplified channel attention
         x = ops.scale_channels(x, s)
-        y = ops.conv(x, self.conv3.packed(scale=self.beta), residual=inp)      # inp + conv3(x)*beta (beta folded)
-        x = ops.conv(self.norm2.run(y), self.conv4.packed(pair=True), act=UR_ACT_GATE)
-        return ops.conv(x, self.conv5.packed(scale=self.gamma), residual=y, gn=True)    # y + conv5(x)*gamma
+        y = ops.conv(x, self.conv3.packed(scale=self.beta), residual=inp, rows=FUSE_LN2D)      # inp + conv3(x)*beta (beta folded)
+        if FUSE_LN2D:
+            x = ops.conv(y, self._ln_folded(self.conv4, self.norm2, True), ln_stats=ops.ln_of(y), act=UR_ACT_GATE)
+        else:
+            x = ops.conv(self.norm2.run(y), self.conv4.packed(pair=True), act=UR_ACT_GATE)
+        return ops.conv(x, self.conv5.packed(scale=self.gamma), residual=y, gn=True, rows=FUSE_LN2D)    # y + conv5(x)*gamma
 
     def forward(self, inp):
         _fresh()
@@ -157,17 +179,37 @@ class AdaNAFV2(nn.Module):
                                      ie.weight.detach().float().flatten(1).contiguous().to(DEV), ie.bias.detach().float().to(DEV))
         return self.__dict__["vecs"]
 
+    def _group_conv_packed(self):
+        """The grouped 3x3 conv (16 groups of 4c/16 channels: cfrm.py:20-21).  Groups narrower than a 64-channel halo chunk would
+        take the generic batched kernel (a 64-byte gather per pixel and tap: 2.19 ms at 256 x 256 x 512); they are densified instead
+        into block-diagonal 128 -> 128 convolutions (zeros outside a group's own block: same sums, 2-4x the MFMA work, all of it
+        at the halo kernel's rate) and run as 4c/128 "groups" of 128 channels."""
+        key = ("pk", "gc", ops.act_dtype())
+        if key not in self.__dict__:
+            gc = self.group_conv
+            w, cg, g = gc.weight.detach().float(), gc.weight.shape[1], gc.groups          # [W, Cg, 3, 3]
+            if cg < 128 and w.shape[0] % 128 == 0 and 128 % cg == 0 and os.environ.get("UR_GC_DENSE", "1") == "1":
+                wd = torch.zeros(w.shape[0], 128, 3, 3)
+                o = torch.arange(w.shape[0])
+                off = ((o // cg) * cg) % 128                                                 # first input channel of o's group inside its 128-block
+                for j in range(cg):
+                    wd[o, off + j] = w[:, j].cpu()
+                self.__dict__[key] = ops.pack_conv(wd, gc.bias, DEV, groups=w.shape[0] // 128, group_halo=True)
+            else:
+                self.__dict__[key] = ops.pack_conv(w, gc.bias, DEV, groups=g)      # (128-channel groups at 64 x 64: 16 half-round halo launches measured slower, 498 vs 324 us)
+        return self.__dict__[key]
+
     def run(self, inp):
         g = self.GROUPS
         wia, bia, wie, bie = self._vecs()
         x = self.group_norm.run(ops.conv(inp, self.conv_in.packed(), gn=True))
-        x = ops.conv(x, self.group_conv.packed(), act=UR_ACT_GELU)             # grouped 3x3 (+GELU)
+        x = ops.conv(x, self._group_conv_packed(), act=UR_ACT_GELU)            # grouped 3x3 (+GELU)
         pooled = ops.avgpool(x)
         s_intra = ops.linear_f32(pooled, wia, bia, groups=g)                   # per-channel scale
         pooled2 = ops.vec_mul_group(pooled, s_intra, s_intra.shape[1])         # mean(x*s) = s*mean(x)
         iga = ops.linear_f32(pooled2, wie, bie)                                # per-group scale
         x = ops.scale_channels(x, ops.vec_mul_group(s_intra, iga, g))
-        return self.nafblock.run(ops.conv(x, self.pwconv.packed(), residual=inp))
+        return self.nafblock.run(ops.conv(x, self.pwconv.packed(), residual=inp, rows=FUSE_LN2D))    # (row sums for the NAFBlock's norm1)
 
     def forward(self, inp):
         _fresh()

@@ -104,9 +104,11 @@ class PackedConv:
     kcm: bool = False  # K order (64-ch chunk, tap, ch) instead of (tap, ch): consecutive K tiles re-read the same pixels (L2)
 
 
-def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=False, groups=1, cin_pad=None, c1=None) -> PackedConv:
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=False, groups=1, cin_pad=None, c1=None, group_halo=False) -> PackedConv:
     """weight: [Cout, Cin/groups, k, k] (nn.Conv2d) or [N, K] (nn.Linear), fp32 master on any device.
-    The repack (OIHW -> O,kh,kw,I; zero padding; a|g interleave; bf16 cast) runs on `dev` with torch copies."""
+    The repack (OIHW -> O,kh,kw,I; zero padding; a|g interleave; bf16 cast) runs on `dev` with torch copies.
+    group_halo: a grouped 3x3 conv whose groups are halo-kernel sized (>= 64 channels in, a multiple of 128 out) - chunk-major
+    weights, one halo launch per group on its channel slice (csrc/igemm.hip conv_impl)."""
     w = weight.detach().to(dev, torch.float32)
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -136,7 +138,8 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=F
         cout_out = half
     # chunk-major K for 3x3 kernels: [Cout][kh*kw][Cin/64][64] -> [Cout][Cin/64][kh*kw][64]; c1 = channels of the first
     # source when the input is a virtual concat (chunks must not straddle it)
-    kcm = kh == 3 and groups == 1 and cin_p % 64 == 0 and (c1 is None or c1 % 64 == 0) and os.environ.get("UR_KCM", "1") == "1"
+    # (grouped convs too when every group is chunk-sized: each group then runs the halo kernel on its channel slice)
+    kcm = kh == 3 and (groups == 1 or (group_halo and cout_p == cout)) and cin_p % 64 == 0 and (c1 is None or c1 % 64 == 0) and os.environ.get("UR_KCM", "1") == "1"
     if kcm:
         wp = wp.reshape(cout_p, kh * kw, cin_p // 64, 64).permute(0, 2, 1, 3)
     return PackedConv(wp.reshape(cout_p, kh * kw * cin_p).to(_act).contiguous(),
