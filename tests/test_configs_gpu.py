@@ -78,17 +78,19 @@ def _check(o, m, img, task, steps, dtypes=("bf16", "fp16"), label="", noise_seed
     return errs
 
 
-# fp16 regression bound on the tightest tensor (zt: measured 7.9-8.2e-4 over the three draws, rounds 4-5): the hard bar is 1e-3,
-# this is the early warning that the margin is being eaten
-FP16_ZT_REGRESSION = 9e-4
+# fp16 regression bound on zt (the hard bar is 1e-3).  Rounds 2-4 measured 7.9-8.2e-4 against an emulated budget of 5.6e-4; round 5 traced
+# the gap (tools/fp16_zt_attrib.py: a dtype-INDEPENDENT 1.6e-3 of eps that vanished with UR_FUSE_LN=0) to a bug, not to rounding: the
+# split-K reduce of a LayerNorm-folded QKV GEMM ignored the transposed-V output, so at B <= 2 the 8x8-level self-attention read an
+# uninitialised V^T (tests/test_ops_gpu.py::test_layernorm_folded_qkv_writes_v_transposed).  Fixed: 5.14-5.16e-4 over the three draws.
+FP16_ZT_REGRESSION = 6.5e-4
 
 
 @pytest.mark.parametrize("img_seed,noise_seed", [(42, 1234), (142, 2234), (242, 3234)])
 def test_config1_sample_512_one_step(full, img_seed, noise_seed):
     """The sample bench.py reports as parity_vs_oracle (seeds 42 / 1234): B=1, 512x512, 1 DDIM step (measured bf16 5.4e-3 / 4.0e-3 /
-    4.2e-3, fp16 7.3e-4 / 8.1e-4 / 5.7e-4) - and two more images / noise draws IN the suite (round 5; ~40 s of CPU oracle each), so
-    that the fp16 margin against the hard 1e-3 is not one sample's luck (round-4 run over the three draws: fp16 zt 8.09e-4 /
-    8.19e-4 / 7.94e-4, z0 7.3-7.5e-4, image 5.7e-4; bf16 z0 5.38-5.45e-3, zt 3.98-4.06e-3, image 4.12-4.15e-3)."""
+    4.0e-3, fp16 7.3e-4 / 5.2e-4 / 5.2e-4 in round 5) - and two more images / noise draws IN the suite (~40 s of CPU oracle each), so
+    that the fp16 margin against the hard 1e-3 is not one sample's luck (round-5 run over the three draws: fp16 zt 5.16e-4 /
+    5.16e-4 / 5.14e-4, z0 7.3-7.4e-4, image 5.2e-4; bf16 z0 5.39-5.46e-3, zt 3.93-4.02e-3, image 4.10-4.15e-3)."""
     o, m = full
     img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(img_seed))
     e = _check(o, m, img, "ir", 1, label=f"configs[1] sample 512x512 / 1 step (seeds {img_seed}, {noise_seed})", noise_seed=noise_seed)

@@ -130,6 +130,23 @@ def test_conv_grouped_colsum_transposed(ops):
     assert rel_l2(vt.float().cpu(), ref[..., 256:].transpose(1, 2)) < TOL_BF16
 
 
+@pytest.mark.parametrize("b,t,c", [(1, 64, 1280), (2, 64, 1280), (8, 64, 1280), (1, 256, 1280), (2, 64, 640)])
+def test_layernorm_folded_qkv_writes_v_transposed(ops, b, t, c):
+    """Fused, LayerNorm-folded QKV GEMM with V written transposed, at the small row counts of the 8x8 / 16x16 levels at B = 1-2 -
+    the launches that go through split-K + the row-wise reduce.  Round 5 found that reduce pass ignoring `yt`: V^T stayed
+    uninitialised for M <= 128 rows (B = 1-2 at the 8x8 level), the dtype-independent 1.6e-3 of eps that kept fp16 zt at 8.1e-4."""
+    g = _gen(b * t + c)
+    x0 = _rb(torch.randn(b * t, c, generator=g)); w0 = _rb(torch.randn(c, c, generator=g) / math.sqrt(c))
+    h2 = ops.linear(x0.to(DT).cuda(), ops.pack_conv(w0, None, "cuda"), rows=True)             # producer: leaves the row sums
+    w = _rb(torch.randn(3 * c, c, generator=g) / math.sqrt(c))
+    ga, be = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    vt = torch.full((b, c, t), float("nan"), dtype=DT, device="cuda")                       # NaN where the kernel does not write
+    qk = ops.linear(ops.carry(h2, h2.view(b, t, c)), ops.pack_linear_ln(w, None, ga, be, 1e-5, "cuda"), ln_stats=ops.ln_of(h2), yt=vt, n_split=2 * c, t_rows=t)
+    ref = F.linear(F.layer_norm(h2.float().cpu(), (c,), ga, be, 1e-5), w).view(b, t, 3 * c)
+    assert rel_l2(qk.float().cpu()[..., :2 * c], ref[..., :2 * c]) < 2 * TOL_BF16
+    assert bool(torch.isfinite(vt.float()).all()) and rel_l2(vt.float().cpu(), ref[..., 2 * c:].transpose(1, 2)) < 2 * TOL_BF16
+
+
 def test_bmm_nt(ops):
     g = _gen(7)
     a = _rb(torch.randn(3, 100, 64, generator=g)); b = _rb(torch.randn(3, 72, 64, generator=g))

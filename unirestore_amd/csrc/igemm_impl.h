@@ -765,6 +765,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const ConvK p) 
         }
       }
       const int co = epi_act(p, 0, m, co_in, v, g);
+      if (p.yt && co >= p.n_split) {                        // transposed columns (V^T of a fused, LayerNorm-folded QKV GEMM) leave through
+        epi_store<F16>(p, 0, m, co, v);                     // the transposing store - round 5: this branch was missing, and a split-K
+        continue;                                           // LN-folded QKV (M <= 128 rows: B = 1-2 at the 8x8 level) never wrote V^T
+      }
       if (p.res) {
         const uint2 rv = *reinterpret_cast<const uint2*>(p.res + (long long)m * p.ldr + co);
         v[0] += Act<F16>::lo(rv.x); v[1] += Act<F16>::hi(rv.x);
