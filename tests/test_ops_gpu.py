@@ -147,6 +147,19 @@ def test_layernorm_folded_qkv_writes_v_transposed(ops, b, t, c):
     assert bool(torch.isfinite(vt.float()).all()) and rel_l2(vt.float().cpu(), ref[..., 2 * c:].transpose(1, 2)) < 2 * TOL_BF16
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,f32", [(8, 64, 64, 320, 4, True), (2, 64, 96, 128, 3, True), (8, 64, 64, 512, 8, False), (4, 32, 64, 64, 32, False)])
+def test_conv_thin_output_halo(ops, n, h, w, cin, cout, f32):
+    """conv_out layers (<= 32 output channels, fp32 or 16-bit): the thin halo tile (round 5) against torch, incl. the zero border."""
+    g = _gen(n * h + cin + cout)
+    x = _rb(torch.randn(n, cin, h, w, generator=g)); wt = _rb(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)); b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1)
+    y = ops.conv(_nhwc(x), ops.pack_conv(wt, b, "cuda"), out_f32=f32)
+    got = y.float().cpu()[..., :cout].permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < (TOL_F32 if f32 else TOL_BF16)
+    if y.shape[-1] > cout:
+        assert float(y.float().cpu()[..., cout:].abs().max()) == 0.0          # padded output channels stay exactly zero
+
+
 def test_bmm_nt(ops):
     g = _gen(7)
     a = _rb(torch.randn(3, 100, 64, generator=g)); b = _rb(torch.randn(3, 72, 64, generator=g))

@@ -72,6 +72,9 @@ static inline int halo_8x32_160(void* kp, hipStream_t s) { return static_cast<Co
 int halo_8x32_128_bf16(void* kp, hipStream_t s);
 int halo_8x32_128_f16(void* kp, hipStream_t s);
 static inline int halo_8x32_128(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? halo_8x32_128_f16(kp, s) : halo_8x32_128_bf16(kp, s); }
+int halo_thin_32_bf16(void* kp, hipStream_t s);
+int halo_thin_32_f16(void* kp, hipStream_t s);
+static inline int halo_thin_32(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? halo_thin_32_f16(kp, s) : halo_thin_32_bf16(kp, s); }
 int himg_16x16_bf16(void* kp, hipStream_t s);
 int himg_16x16_f16(void* kp, hipStream_t s);
 static inline int himg_16x16(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? himg_16x16_f16(kp, s) : himg_16x16_bf16(kp, s); }
@@ -104,6 +107,12 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
       return urk::halo_8x32_128(&k, s);
     }
   }
+  // conv_out layers: <= 32 output channels (fp32 or 16-bit) of a 3x3 / stride 1 / pad 1 conv with chunk-major weights
+  static const bool no_thin = getenv("UR_IGEMM_NOTHIN") != nullptr;
+  if (!no_thin && !no_halo && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && !pair && k.nbatch == 1 && !k.ups && k.C2 == 0 &&
+      k.Cout <= 32 && k.OW % 32 == 0 && k.OH % 8 == 0 && k.OH == k.H && k.OW == k.W && !k.yt && !k.gn_part && !k.gn_ab && !k.row_stats && !k.ln_stats &&
+      !k.bias_img && (long long)k.N * (k.OH / 8) * (k.OW / 32) >= 128)
+    return urk::halo_thin_32(&k, s);
   static const bool no_himg = getenv("UR_IGEMM_NOHIMG") != nullptr;
   if (!no_himg && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && k.staged_ok_ && !pair && k.nbatch == 1 && !k.ups &&
       k.OH == k.H && k.OW == k.W && !k.yt && k.Cout % 128 == 0 && k.nk >= 36) {

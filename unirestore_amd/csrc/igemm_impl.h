@@ -154,7 +154,7 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ConvK& p, f32x16 (&a
     if (pair && (a & 1)) continue;
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
-      int m = m0 + wm * WTM + b * 32 + mrow;
+      int m = tile_row_to_m(p, m0, wm * WTM + b * 32 + mrow);          // (patch tiles of the halo kernels: rows run over an image window)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         int co_in = n0 + wn * WTN + a * 32 + rg * 8 + fhalf * 4;
@@ -1428,7 +1428,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
   constexpr int NW = WM * WN, TW = 32, BM = TH * TW, PW = TW + 2, HPIX = (TH + 2) * PW;   // 340 (TH=8) / 204 (TH=4) halo pixels
   constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);                              // tap slots that carry a halo piece
   constexpr int HPIECES = HSLOTS * NW, HBYTES = HPIECES * 1024;   // surplus pieces are never read (zero fill)
-  constexpr int WBYTES = BN * 128, WPIECES = BN / 8, WPW = (WPIECES + NW - 1) / NW;   // weight pieces per wave per tile
+  // (ring slot = at least one piece per wave: in the thin tile, BN = 32, waves >= BN / 8 issue an all-zero piece behind the tile's rows)
+  constexpr int WBYTES = BN * 128 > NW * 1024 ? BN * 128 : NW * 1024, WPIECES = BN / 8, WPW = (WPIECES + NW - 1) / NW;   // weight pieces per wave per tile
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = NW * 64;
   static_assert((NW == 8 || NW == 4) && WTM % 32 == 0 && WTN % 32 == 0 && HSLOTS <= 8, "wave layout");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1723,7 +1724,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
 #elif UR_HALO_ABL == 4                                        // timing-only: no epilogue (one store keeps the loop alive)
   if (acc[0][0][0] == 123.456f) reinterpret_cast<uint16_t*>(p.y)[0] = 1;
 #else
-  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+  // (BN == 32: the thin tile of the conv_out layers - fp32 output, 4-8 channels - leaves through the direct stores)
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, BN == 32>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 #endif
 }
 
@@ -2005,6 +2007,33 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const
 #else
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 #endif
+}
+
+// Thin-N halo launch (round 5): 3x3 convolutions onto <= 32 output channels - the three conv_out layers (VAE decoder 128 -> 3 at 512 x 512:
+// 747 us at 52 TF/s on the generic 256 x 32 kernel, which gathers every pixel nine times; UNet 320 -> 4; VAE encoder 512 -> 8).  Same
+// patch-in-LDS loader as every halo conv (self-loading kernel: with one weight piece per wave and tap there is nothing for a loader wave to
+// do), tile = 8 x 32 pixels x 32 channel rows (rows >= Cout read zero through the descriptor's range check), hipcc-scheduled 1 x 1 fragment
+// body.  The launch is bound by reading the input once (x 1.3 for the halo), not by the matrix pipe.
+template <int TH, int BN, int WM, int WN>
+int launch_halo_thin(ConvK& k, hipStream_t s) {
+  constexpr int NW = WM * WN, HPIX = (TH + 2) * 34, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
+  constexpr int HBYTES = HSLOTS * NW * 1024;
+  constexpr int lds = 2 * HBYTES + 3 * (BN * 128 > NW * 1024 ? BN * 128 : NW * 1024) + 2048;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  k.prologue_ok = 0;
+  k.tiles_m = k.N * (k.OH / TH) * (k.OW / 32);
+  k.tiles_n = (k.Cout + BN - 1) / BN;
+  k.splitk = 1;
+  k.nk_per_split = k.nk;
+  set_gn_plan(k, false, 0);
+  if (k.dry) { k.plan_tn = k.tiles_n; return UR_OK; }
+  k.patch_tw = 32;
+  static ur::DeviceOnce attr_once;      // the attribute is per device
+  if (auto once_guard = attr_once.first()) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, 1), dim3(NW * 64), lds, s, k));
+  return ur::check_launch("ur_conv2d_nhwc");
 }
 
 template <int TH, int BN, int WM, int WN>
