@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from unirestore_amd import ops
 from ab_micro import gtime
-for b, t, c in ((8, 4096, 320), (8, 1024, 640), (8, 256, 1280), (8, 64, 1280)):
+for b, t, c in ((8, 4096, 320), (8, 1024, 640), (8, 256, 1280), (8, 64, 1280), (160, 4096, 256), (160, 1024, 256), (160, 256, 512)):
     x = torch.randn(b, t, c, device="cuda").to(torch.bfloat16)
     pc = ops.pack_conv(torch.randn(3 * c, c) / c ** 0.5, torch.randn(3 * c), "cuda")
     vt = torch.empty(b, c, t, device="cuda", dtype=torch.bfloat16)
