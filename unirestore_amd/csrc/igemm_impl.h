@@ -316,11 +316,19 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
     const bool multi = nimg_tile > 1, hasact = p.act != UR_ACT_NONE;
 #define UR_EPI_PASS(PAIR, LN, MULTI, YT, ACT) \
     epi_frag_pass<FM, FN, WTM, WTN, BM, BN, SROW, PAIR, LN, MULTI, YT, ACT, F16>(p, acc, m0, n0, c0, wm, wn, lane, gb, smem, sbias, scol, srow)
-    if (CLS == 0) { if (hasact) UR_EPI_PASS(0, 0, 0, 0, 1); else UR_EPI_PASS(0, 0, 0, 0, 0); }
-    else if (pair) { if (ln) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0); }     // never with multi / yt (host-checked)
-    else if (yt) UR_EPI_PASS(0, 2, 0, 1, 2);                                                    // fused QKV with transposed V
-    else if (multi) UR_EPI_PASS(0, 0, 1, 0, 2);                                                 // per-image bias rows
-    else UR_EPI_PASS(0, 1, 0, 0, 2);                                                            // LayerNorm consumer
+    if constexpr (CLS == 0) { if (hasact) UR_EPI_PASS(0, 0, 0, 0, 1); else UR_EPI_PASS(0, 0, 0, 0, 0); }
+    else if constexpr (PAIRC) {                                 // pair-only kernels (256-wide GEGLU / SimpleGate tiles, 128-160 accumulator registers):
+      if (ln) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0);      // nothing else is compiled in - every extra instance moved their allocation (704 B of scratch once)
+    } else {
+      if (pair) { if (ln) UR_EPI_PASS(1, 1, 0, 0, 0); else UR_EPI_PASS(1, 0, 0, 0, 0); }        // never with multi / yt (host-checked)
+      else if (yt) {                                                                            // fused QKV with transposed V
+        if (hasact) UR_EPI_PASS(0, 2, 0, 1, 2);
+        else if (ln) UR_EPI_PASS(0, 1, 0, 1, 0);                // (the two production forms with their flags compiled in: the all-run-time
+        else UR_EPI_PASS(0, 0, 0, 1, 0);                        //  instance cost 3 us on 8192 x 1920 x 640 and 50 us on the Controller's 655 360-row QKV)
+      }
+      else if (multi) UR_EPI_PASS(0, 0, 1, 0, 2);                                               // per-image bias rows
+      else UR_EPI_PASS(0, 1, 0, 0, 2);                                                          // LayerNorm consumer
+    }
 #undef UR_EPI_PASS
   }
   if (p.dbg & 16) return;
