@@ -326,8 +326,9 @@ __device__ __forceinline__ void staged_epilogue(const ConvK& p, f32x16 (&acc)[FN
         else if (ln) UR_EPI_PASS(0, 1, 0, 1, 0);                // (the two production forms with their flags compiled in: the all-run-time
         else UR_EPI_PASS(0, 0, 0, 1, 0);                        //  instance cost 3 us on 8192 x 1920 x 640 and 50 us on the Controller's 655 360-row QKV)
       }
-      else if (multi) UR_EPI_PASS(0, 0, 1, 0, 2);                                               // per-image bias rows
-      else UR_EPI_PASS(0, 1, 0, 0, 2);                                                          // LayerNorm consumer
+      else if (multi) { if (hasact) UR_EPI_PASS(0, 0, 1, 0, 2); else UR_EPI_PASS(0, 0, 1, 0, 0); }     // per-image bias rows
+      else if (hasact) UR_EPI_PASS(0, 1, 0, 0, 2);                                              // LayerNorm consumer
+      else UR_EPI_PASS(0, 1, 0, 0, 0);
     }
 #undef UR_EPI_PASS
   }
