@@ -50,6 +50,74 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restri
   }
 }
 
+// Strip form (round 5): one thread = 8 channels of FOUR consecutive output pixels of a row.  The 3 x 6 input window is loaded once
+// (18 16-byte loads per channel half instead of 36) and the nine weights of the thread's channels sit in registers; per output pixel the
+// taps are added in the same (dy, dx) order as in the one-pixel kernel above, so the results are bit-identical.  Needs W % 4 == 0.
+template <bool F16>
+__global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, uint16_t* __restrict__ y, int N,
+                                                              int H, int W, int C, int gate) {
+  constexpr int S = 4;
+  const int Cout = gate ? C / 2 : C;
+  const int CV = Cout >> 3, WS = W / S;
+  const long long total = (long long)N * H * WS * CV;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int v = (int)(i % CV);
+    long long r = i / CV;
+    const int ow0 = (int)(r % WS) * S;
+    r /= WS;
+    const int oh = (int)(r % H), n = (int)(r / H);
+    float acc[2][S][8];
+    const int halves = gate ? 2 : 1;
+    for (int hf = 0; hf < halves; ++hf) {
+      const int c0 = v * 8 + hf * Cout;
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + c0), b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+#pragma unroll
+      for (int sx = 0; sx < S; ++sx) {
+        float* a = acc[hf][sx];
+        a[0] = b0.x; a[1] = b0.y; a[2] = b0.z; a[3] = b0.w; a[4] = b1.x; a[5] = b1.y; a[6] = b1.z; a[7] = b1.w;
+      }
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int ih = oh + dy - 1;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        uint4 raw[S + 2];
+#pragma unroll
+        for (int j = 0; j < S + 2; ++j) {
+          const int iw = ow0 + j - 1;
+          raw[j] = (unsigned)iw < (unsigned)W ? *reinterpret_cast<const uint4*>(x + (((long long)n * H + ih) * W + iw) * C + c0) : make_uint4(0, 0, 0, 0);
+        }
+        float wk[3][8];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float* wp = w + (dy * 3 + dx) * C + c0;
+          const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+          wk[dx][0] = w0.x; wk[dx][1] = w0.y; wk[dx][2] = w0.z; wk[dx][3] = w0.w; wk[dx][4] = w1.x; wk[dx][5] = w1.y; wk[dx][6] = w1.z; wk[dx][7] = w1.w;
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int sx = 0; sx < S; ++sx) {
+            const int iw = ow0 + sx + dx - 1;
+            if ((unsigned)iw >= (unsigned)W) continue;          // (zero padding: the tap is skipped, as in the one-pixel kernel)
+            float f[8];
+            unpack8t<F16>(raw[sx + dx], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[hf][sx][e] += f[e] * wk[dx][e];
+          }
+      }
+    }
+#pragma unroll
+    for (int sx = 0; sx < S; ++sx) {
+      if (gate) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[0][sx][e] *= acc[1][sx][e];
+      }
+      *reinterpret_cast<uint4*>(y + ((((long long)n * H + oh) * W + ow0 + sx) * Cout) + v * 8) = pack8t<F16>(acc[0][sx]);
+    }
+  }
+}
+
 template <bool F16>
 __global__ __launch_bounds__(256) void scale_channels_kernel(const uint16_t* __restrict__ x, const float* __restrict__ s,
                                                              const uint16_t* __restrict__ res, uint16_t* __restrict__ y,
@@ -350,6 +418,12 @@ int ur_dwconv3x3_nhwc(const void* x, const float* w9c, const float* bias, void* 
   const double elems = (double)N * H * W * C;
   ur::ProfScope prof("dwconv3x3", 18.0 * elems, 2.0 * elems * (gate ? 1.5 : 2.0), s);
   const long long total = (long long)N * H * W * ((gate ? C / 2 : C) / 8);
+  static const bool no_strip = getenv("UR_DW_NOSTRIP") != nullptr;
+  if (!no_strip && W % 4 == 0) {
+    UR_DT_SWITCH(dtype, hipLaunchKernelGGL(dwconv3x3_strip_kernel<F16>, dim3(nblocks(total / 4)), dim3(256), 0, s, (const uint16_t*)x, w9c, bias, (uint16_t*)y,
+                       N, H, W, C, gate));
+    return ur::check_launch("ur_dwconv3x3_nhwc");
+  }
   UR_DT_SWITCH(dtype, hipLaunchKernelGGL(dwconv3x3_kernel<F16>, dim3(nblocks(total)), dim3(256), 0, s, (const uint16_t*)x, w9c, bias, (uint16_t*)y, N,
                      H, W, C, gate));
   return ur::check_launch("ur_dwconv3x3_nhwc");
