@@ -187,11 +187,23 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
   const float* wr = w + (long long)n * Kg;
   for (int m0 = 0; m0 < M; m0 += 8) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = lane; k < Kg; k += 64) {
-      const float wv = wr[k];
+    // four k per lane and iteration with all 36 loads issued before the first use (one load per dependent step made this
+    // kernel K / 64 serialised memory round trips: 24 us for a 512-wide gate MLP); same per-lane summation order
+    for (int k0 = lane; k0 < Kg; k0 += 256) {
+      float wv[4], xv[4][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (m0 + j < M) acc[j] += wv * x[(long long)(m0 + j) * K + g * Kg + k];
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 64 * u;
+        const bool kin = k < Kg;
+        wv[u] = kin ? wr[k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[u][j] = (kin && m0 + j < M) ? x[(long long)(m0 + j) * K + g * Kg + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k0 + 64 * u < Kg && m0 + j < M) acc[j] += wv[u] * xv[u][j];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
