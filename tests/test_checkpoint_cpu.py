@@ -124,3 +124,16 @@ def test_hf_unet_into_spade_model_and_deprecated_vae_names(tmp_path):
     save_file(bad, str(tmp_path / "hf" / "unet" / "diffusion_pytorch_model.safetensors"))
     with pytest.raises(RuntimeError):
         ck.load_hf_weights(dst, str(tmp_path / "hf"), components=("unet",))
+
+
+def test_per_sample_timestep_contract():
+    """Operator-level timesteps (controller.py:193-194, base_model.py:211-216): one value for the batch or one per sample."""
+    import pytest
+    import torch
+    from unirestore_amd.modules.model import _per_sample_timesteps
+    assert _per_sample_timesteps(torch.tensor([999]), 4) == [999]
+    assert _per_sample_timesteps(torch.tensor(749), 3) == [749]
+    assert _per_sample_timesteps(torch.tensor([5, 5, 5]), 3) == [5]                  # all equal collapses to the shared-row form
+    assert _per_sample_timesteps(torch.tensor([999, 249, 749]), 3) == [999, 249, 749]
+    with pytest.raises(ValueError):
+        _per_sample_timesteps(torch.tensor([999, 249]), 3)
