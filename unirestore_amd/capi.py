@@ -6,6 +6,11 @@ import time, so a GPU run can never silently execute something else.
 import ctypes as C
 import os
 
+# torch FIRST: it brings its own HIP runtime (torch/lib/libamdhip64.so).  If libunirestore_hip.so is dlopen'ed before torch, the
+# process ends up with /opt/rocm's runtime bound to this library and torch's bound to torch - and the library's first launch fails
+# with "no ROCm-capable device is detected" (seen with __graft_entry__.build() followed by smoke() in one process, round 5).
+import torch  # noqa: F401  (load order only)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB") or os.path.join(_HERE, "libunirestore_hip.so")     # UR_LIB: an A/B build of the same ABI
 
