@@ -160,6 +160,99 @@ def test_conv_thin_output_halo(ops, n, h, w, cin, cout, f32):
         assert float(y.float().cpu()[..., cout:].abs().max()) == 0.0          # padded output channels stay exactly zero
 
 
+@pytest.mark.parametrize("m,k,n", [(64, 1280, 1280), (128, 1280, 3840), (512, 2560, 1280), (256, 640, 1920), (2048, 5120, 1280), (192, 1280, 640), (64, 1280, 3840),
+                                   (64, 512, 1536), (512, 2560, 3840)])
+@pytest.mark.parametrize("feat", ["plain", "res", "res+rows", "ln", "ln+res+rows", "ln+yt", "yt", "gn+res", "ln+gn", "gelu", "ln+geglu"])
+def test_linear_feature_matrix_small_m(ops, m, k, n, feat):
+    """Every epilogue feature combination the model uses, at the SMALL row counts (B = 1-2 at the 8x8 / 16x16 levels, long K) where the
+    dispatcher goes through split-K and its reduce kernels - the corner that hid the round-5 V^T bug.  Against fp64 torch."""
+    g = _gen(m + k + n + len(feat))
+    f = set(feat.split("+"))
+    if "yt" in f and n % 12:
+        pytest.skip("transposed V needs N = 3 x C")
+    pair = "geglu" in f
+    x0 = _rb(torch.randn(m, 96, generator=g)); w0 = _rb(torch.randn(k, 96, generator=g) / math.sqrt(96))
+    x = ops.linear(x0.to(DT).cuda(), ops.pack_conv(w0, None, "cuda"), rows="ln" in f)          # producer (leaves row sums when a LayerNorm consumer follows)
+    xs = x.double().cpu()
+    w = _rb(torch.randn(n, k, generator=g) / math.sqrt(k)); b = torch.randn(n, generator=g)
+    kw = {}
+    if "ln" in f:
+        ga, be = 1 + 0.1 * torch.randn(k, generator=g), 0.1 * torch.randn(k, generator=g)
+        pc = ops.pack_linear_ln(w, b, ga, be, 1e-5, "cuda", pair=pair)
+        kw["ln_stats"] = ops.ln_of(x)
+        ref = F.linear(F.layer_norm(xs, (k,), ga.double(), be.double(), 1e-5), w.double(), b.double())
+    else:
+        pc = ops.pack_conv(w, b, "cuda", pair=pair)
+        ref = F.linear(xs, w.double(), b.double())
+    if "gelu" in f:
+        kw["act"] = ops.UR_ACT_GELU; ref = F.gelu(ref)
+    if pair:
+        kw["act"] = ops.UR_ACT_GEGLU
+        a, gt = ref.chunk(2, -1); ref = a * F.gelu(gt)
+    nout = ref.shape[1]
+    if "res" in f:
+        r = _rb(torch.randn(m, nout, generator=g)); kw["residual"] = r.to(DT).cuda(); ref = ref + r.double()
+    if "rows" in f:
+        kw["rows"] = True
+    if "gn" in f:
+        kw.update(gn=True, gn_hw=(1, m))
+    vt = None
+    if "yt" in f:
+        c = n // 3
+        vt = torch.full((1, c, m), float("nan"), dtype=DT, device="cuda")
+        kw.update(yt=vt, n_split=2 * c, t_rows=m)
+    y = ops.linear(x.view(1, m, k) if vt is not None else x, pc, **kw)
+    yy = y.reshape(m, -1).double().cpu()
+    tol = 2 * TOL_BF16 if "ln" in f else TOL_BF16
+    ncmp = 2 * (n // 3) if vt is not None else nout
+    assert rel_l2(yy[:, :ncmp], ref[:, :ncmp]) < tol
+    if vt is not None:
+        assert bool(torch.isfinite(vt.float()).all()) and rel_l2(vt[0].double().cpu(), ref[:, ncmp:].t()) < tol
+    if "rows" in f:
+        st, parts = ops.ln_of(y)
+        ss = st.view(parts, m, 2).double().sum(0).cpu()
+        assert rel_l2(ss[:, 0], yy.sum(1)) < 1e-5 and rel_l2(ss[:, 1], (yy ** 2).sum(1)) < 1e-5
+    if "gn" in f:
+        plane, parts = ops.gn_of(y)
+        s2 = plane.double().sum(1)[0].cpu()
+        assert rel_l2(s2[:, 0], yy.sum(0)) < 1e-4 and rel_l2(s2[:, 1], (yy ** 2).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("n,hw,cin,cout,cat", [(1, 8, 1280, 1280, 0), (4, 8, 1280, 1280, 1280), (2, 16, 1280, 1280, 0), (1, 16, 640, 1280, 640), (1, 32, 640, 640, 0),
+                                               (2, 32, 320, 640, 320), (1, 64, 320, 320, 0)])
+@pytest.mark.parametrize("feat", ["plain", "res+gn", "silu", "gn", "rowbias+gn"])
+def test_conv3x3_feature_matrix_small_batch(ops, n, hw, cin, cout, cat, feat):
+    """3x3 convs at B = 1-4 on the UNet's map sizes (whole-image halo tiles, channel-chunk split-K + the GroupNorm reduce pass, virtual
+    concat) with the epilogue features the resnets use, against fp64 torch: the small-batch corner the B = 8 bench never visits."""
+    g = _gen(n * hw + cin + cout + len(feat))
+    f = set(feat.split("+"))
+    x = _rb(torch.randn(n, cin, hw, hw, generator=g))
+    x2 = _rb(torch.randn(n, cat, hw, hw, generator=g)) if cat else None
+    wt = _rb(torch.randn(cout, cin + cat, 3, 3, generator=g) / math.sqrt(9 * (cin + cat))); b = torch.randn(cout, generator=g)
+    xin = torch.cat([x, x2], 1) if cat else x
+    ref = F.conv2d(xin.double(), wt.double(), None, padding=1)
+    kw = {}
+    if "rowbias" in f:                                       # per-image bias rows (time embeddings of a schedule-batched pass)
+        rows = torch.randn(n, cout, generator=g)
+        kw["bias"] = rows.cuda()
+        ref = ref + rows.double()[:, :, None, None]
+    else:
+        ref = ref + b.double()[None, :, None, None]
+    if "silu" in f:
+        kw["act"] = ops.UR_ACT_SILU; ref = F.silu(ref)
+    if "res" in f:
+        r = _rb(torch.randn(n, cout, hw, hw, generator=g)); kw["residual"] = _nhwc(r); ref = ref + r.double()
+    if "gn" in f:
+        kw["gn"] = True
+    y = ops.conv(_nhwc(x), ops.pack_conv(wt, b, "cuda", c1=cin if cat else None), x2=_nhwc(x2) if cat else None, **kw)
+    got = _nchw(y).double()
+    assert rel_l2(got, ref) < TOL_BF16
+    if "gn" in f:
+        plane, parts = ops.gn_of(y)
+        s2 = plane.double().sum(1).cpu()                      # [n, cout, 2]
+        assert rel_l2(s2[..., 0], got.sum((2, 3))) < 1e-4 and rel_l2(s2[..., 1], (got ** 2).sum((2, 3))) < 1e-5
+
+
 def test_bmm_nt(ops):
     g = _gen(7)
     a = _rb(torch.randn(3, 100, 64, generator=g)); b = _rb(torch.randn(3, 72, 64, generator=g))
