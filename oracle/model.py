@@ -230,6 +230,8 @@ class DiffUIE(nn.Module):
                 ts = torch.tensor([int(t)], dtype=torch.int64)
                 eps = self.base_model(zt, self.controller(z0, ts), ts)
                 zt = schedule.ddim_step(eps, int(t), zt, self.num_inference_steps)
+                if getattr(self, "trace_zt", None) is not None:
+                    self.trace_zt.append(zt.clone())                          # per-step latents for the trajectory parity test
         preds = self.ae.decode(zt, mids, task)[..., :h, :w]
         preds = F.interpolate(preds, (org_h, org_w), mode="bicubic", align_corners=False, antialias=False)
         return (preds, z0, zt) if return_latents else preds

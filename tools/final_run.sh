@@ -12,7 +12,7 @@ python tools/summarize_rocprof.py $f gpurun_out/${T}_rocprofv3_kernel_stats.csv 
 rm -rf gpurun_out/prof
 timeout 600 python tools/prof_shapes.py 110 > gpurun_out/${T}_per_shape_hip_events.txt 2>&1
 python tools/phase_times.py 2>&1 | grep -v amdgpu > gpurun_out/${T}_phase_times.txt
-bash tools/r5_steptrace.sh > /dev/null 2>&1; cp gpurun_out/r5_step_kernel_trace.txt gpurun_out/${T}_step_kernel_trace.txt
+bash tools/r5/r5_steptrace.sh > /dev/null 2>&1; cp gpurun_out/r5_step_kernel_trace.txt gpurun_out/${T}_step_kernel_trace.txt
 python - <<PY
 import json
 d=json.loads(open("gpurun_out/${T}_bench.json").read().strip().splitlines()[-1])

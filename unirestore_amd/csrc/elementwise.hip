@@ -356,7 +356,9 @@ __global__ __launch_bounds__(256) void image_unpad_resize_kernel(const void* __r
         }
         v += wy[a] * rowv;
       }
-      if (quantize) v = fminf(fmaxf(rintf(v * 255.f), 0.f), 255.f) / 255.f;     // torch.round = half-to-even = rintf
+      // torch.round = half-to-even = rintf.  A non-finite value stays non-finite (torch.clamp propagates NaN; fmaxf would turn it into a
+      // black pixel and hide an fp16 overflow from DiffUIE.forward's finite check): NaN and +-inf both leave as NaN.
+      if (quantize) v = (fabsf(v) <= 3.0e38f) ? fminf(fmaxf(rintf(v * 255.f), 0.f), 255.f) / 255.f : __builtin_nanf("");
       out[(((long long)n * C + c) * OH + oy) * OW + ox] = v;
     }
   }

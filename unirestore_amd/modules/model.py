@@ -329,6 +329,7 @@ class DiffUIE(nn.Module):
         self.tedit = tedit if tedit else None
         self.ae = SkipConnectedAutoEncoder(AutoencoderKL(**(vae_cfg or {})), self.fr_type, self.tedit, fr_depths)
         self.use_graph = use_graph
+        self.trace_zt = None                   # parity instrumentation: a list collects zt after every DDIM step (eager runs only)
         self.check_fp16_overflow = True        # fp16 only: one isfinite reduction over the restored images per forward (+ a sync)
         self.batch_controller = os.environ.get("UR_BATCH_CONTROLLER", "1") == "1"
         self._graphs = {}
@@ -450,6 +451,8 @@ class DiffUIE(nn.Module):
                 eps = self.base_model.run(ztb, control, i)
                 c_x, c_e = schedule.ddim_coefficients(int(t), self.num_inference_steps)
                 ops.ddim_step_(zt, ztb, eps, lat, c_x, c_e)
+                if self.trace_zt is not None and not torch.cuda.is_current_stream_capturing():
+                    self.trace_zt.append(ops.nhwc_to_nchw(zt, c=lat).cpu())      # parity instrumentation (eager runs only)
         preds = self.ae.decode_run(zt, mids, task, out_plan=((h, w), tuple(images.shape[-2:]), quantize))
         return preds, z0, zt
 
