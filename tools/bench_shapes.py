@@ -52,18 +52,25 @@ shapes = [
     ("vae c3 128->128@512", 512, 512, 128, 128, 3, 1, 10), ("vae c3 256->256@256", 256, 256, 256, 256, 3, 1, 8),
     ("vae c3 512->512@128", 128, 128, 512, 512, 3, 1, 10), ("vae c3 512->512@64", 64, 64, 512, 512, 3, 1, 14),
     ("vae c3 256->256@512up", 256, 256, 256, 256, 3, 1, 1), ("vae c3 128->8@512", 512, 512, 128, 8, 3, 1, 1),
+    # round 6: the slow half of the conv3x3 family (stride 2, the 8x8 -> 16x16 upsampling conv, the schedule-batched Controller)
+    ("s2 c3 320->320@64", 64, 64, 320, 320, 3, 2, 1 * S), ("s2 c3 640->640@32", 32, 32, 640, 640, 3, 2, 1 * S),
+    ("s2 c3 1280->1280@16", 16, 16, 1280, 1280, 3, 2, 1 * S), ("unet c3 1280->1280@16up", 8, 8, 1280, 1280, 3, 1, 1 * S),
+    ("ctrlB c3 256->256@64 x20", 64, 64, 256, 256, 3, 1, 6, 20), ("ctrlB c3 256->256@32 x20", 32, 32, 256, 256, 3, 1, 6, 20),
+    ("ctrlB c3 512->512@16 x20", 16, 16, 512, 512, 3, 1, 3, 20), ("ctrlB c3 512->512@8 x20", 8, 8, 512, 512, 3, 1, 8, 20),
 ]
 only = os.environ.get("ONLY")
 tot = 0.0
 print(f"{'shape':32s} {'M':>8s} {'us':>9s} {'TF/s':>7s} {'cnt':>5s} {'ms/fwd':>8s}")
-for name, h, w, cin, cout, k, stride, cnt in shapes:
+REPS = int(os.environ.get("REPS", 20))
+for name, h, w, cin, cout, k, stride, cnt, *bm in shapes:
     if only and only not in name: continue
     up = name.endswith("up")
-    x = torch.randn(B, h, w, cin, device="cuda").to(torch.bfloat16)
+    Bx = B * (bm[0] if bm else 1)
+    x = torch.randn(Bx, h, w, cin, device="cuda").to(torch.bfloat16)
     pc = ops.pack_conv(torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5, torch.randn(cout), "cuda")
-    f = lambda: ops.conv(x, pc, upsample=up)
-    us = gtime(f)
-    m = B * h * w * (4 if up else 1)
+    f = lambda: ops.conv(x, pc, upsample=up, stride=stride)       # stride 2: the UNet's Downsample2D (padding 1)
+    us = gtime(f, REPS)
+    m = Bx * h * w * (4 if up else 1) // (stride * stride)
     fl = 2.0 * m * cout * cin * k * k
     tot += us * cnt / 1e3
     print(f"{name:32s} {m:8d} {us:9.1f} {fl / us / 1e6:7.1f} {cnt:5d} {us * cnt / 1e3:8.2f}")
