@@ -106,6 +106,10 @@ typedef struct ur_conv_desc {
   long long bias_img_stride; /* 0: one bias row; else bias row of image n = m/(OH*OW) is bias + n*stride
                                 (per-sample time embeddings, unifie.py:91-105) */
   int dtype;            /* UR_DT_BF16 | UR_DT_F16: type of x, x2, w, residual, y (unless out_f32), yt */
+  const void* w_frag;   /* optional second packing of the SAME weights for the weight-streaming kernel of the 8 x 8 maps (3x3, stride 1,
+                           Cout % 128 == 0, (C1+C2) % 256 == 0), or NULL: MFMA-fragment-major
+                           [Cout/128][(C1+C2)/64][tap 9][k-step 4][row block 4][lane 64][8], lane = (cout % 32) + 32 * ((cin % 16) / 8),
+                           element = cin % 8 - one coalesced 1-KiB load per 32 x 16 weight fragment (csrc/conv_wstream.hip) */
 } ur_conv_desc;
 
 int ur_conv2d_nhwc(const ur_conv_desc* d, ur_stream_t stream);

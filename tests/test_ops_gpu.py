@@ -253,6 +253,45 @@ def test_conv3x3_feature_matrix_small_batch(ops, n, hw, cin, cout, cat, feat):
         assert rel_l2(s2[..., 0], got.sum((2, 3))) < 1e-4 and rel_l2(s2[..., 1], (got ** 2).sum((2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("n,cin,cout,cat", [(8, 1280, 1280, 0), (8, 1280, 1280, 1280), (1, 512, 128, 0), (3, 768, 256, 256), (16, 512, 1280, 0), (5, 1280, 640, 0)])
+@pytest.mark.parametrize("feat", ["plain", "res+gn", "rowbias+gn+silu"])
+def test_conv3x3_weight_stream_8x8(ops, n, cin, cout, cat, feat):
+    """The weight-streaming kernel of the 8 x 8 maps (csrc/conv_wstream.hip: fragment-major weights straight to registers, one chunk per
+    wave, in-workgroup exchange, nchunk / 4 partial planes + the reduce pass) at the bench's B = 8 and at odd / small / large image counts
+    (a half-empty image pair, 1 - 16 images), single source and virtual concat, against fp64 torch."""
+    g = _gen(n * 13 + cin + cout + cat + len(feat))
+    f = set(feat.split("+"))
+    x = _rb(torch.randn(n, cin, 8, 8, generator=g))
+    x2 = _rb(torch.randn(n, cat, 8, 8, generator=g)) if cat else None
+    wt = _rb(torch.randn(cout, cin + cat, 3, 3, generator=g) / math.sqrt(9 * (cin + cat))); b = torch.randn(cout, generator=g)
+    xin = torch.cat([x, x2], 1) if cat else x
+    ref = F.conv2d(xin.double(), wt.double(), None, padding=1)
+    kw = {}
+    if "rowbias" in f:
+        rows = torch.randn(n, cout, generator=g)
+        kw["bias"] = rows.cuda()
+        ref = ref + rows.double()[:, :, None, None]
+    else:
+        ref = ref + b.double()[None, :, None, None]
+    if "silu" in f:
+        kw["act"] = ops.UR_ACT_SILU; ref = F.silu(ref)
+    if "res" in f:
+        r = _rb(torch.randn(n, cout, 8, 8, generator=g)); kw["residual"] = _nhwc(r); ref = ref + r.double()
+    if "gn" in f:
+        kw["gn"] = True
+    pc = ops.pack_conv(wt, b, "cuda", c1=cin if cat else None)
+    y = ops.conv(_nhwc(x), pc, x2=_nhwc(x2) if cat else None, **kw)
+    assert pc.w_frag is not None, "this shape must take the weight-streaming kernel"
+    y2 = ops.conv(_nhwc(x), pc, x2=_nhwc(x2) if cat else None, **kw)
+    assert torch.equal(y, y2)                                  # fixed-order exchange + reduce: bit-deterministic
+    got = _nchw(y).double()
+    assert rel_l2(got, ref) < TOL_BF16
+    if "gn" in f:
+        plane, parts = ops.gn_of(y)
+        s2 = plane.double().sum(1).cpu()
+        assert rel_l2(s2[..., 0], got.sum((2, 3))) < 1e-4 and rel_l2(s2[..., 1], (got ** 2).sum((2, 3))) < 1e-5
+
+
 def test_bmm_nt(ops):
     g = _gen(7)
     a = _rb(torch.randn(3, 100, 64, generator=g)); b = _rb(torch.randn(3, 72, 64, generator=g))

@@ -1,10 +1,11 @@
-"""Workgroup time line of the halo conv (A/B build -DUR_HALO_ABL=7): UR_LIB=unirestore_amd/ab/libur_tl.so python tools/halo_wg_timeline.py [cin cout]"""
+"""Workgroup time line of the halo conv (A/B build -DUR_HALO_ABL=7): UR_LIB=unirestore_amd/ab/libur_tl.so python tools/halo_wg_timeline.py [cin cout [hw]]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from unirestore_amd import ops
 cin, cout = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (320, 320)
-x = torch.randn(8, 64, 64, cin, device="cuda").to(torch.bfloat16)
+hw = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+x = torch.randn(8, hw, hw, cin, device="cuda").to(torch.bfloat16)
 pc = ops.pack_conv(torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5, torch.randn(cout), "cuda")
 for _ in range(3):
     y = ops.conv(x, pc)

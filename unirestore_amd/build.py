@@ -17,6 +17,7 @@ EXTRA = os.environ.get("UR_EXTRA_FLAGS", "").split()
 IGEMM_UNITS = ["igemm_v2.hip", "igemm_halo.hip", "igemm_v1a.hip", "igemm_v1b.hip", "igemm_g1.hip"]     # slowest first
 # (source, extra flags, object name): every igemm instantiation unit is built once per 16-bit type
 SOURCES = [(u, [f"-DUR_TU_F16={t}"], u.replace(".hip", "_f16.o" if t else "_bf16.o")) for u in IGEMM_UNITS for t in (0, 1)] + \
+          [("conv_wstream.hip", [f"-DUR_TU_F16={t}"], "conv_wstream_f16.o" if t else "conv_wstream_bf16.o") for t in (0, 1)] + \
           [("attention.hip", [f"-DUR_TU_F16={t}"], "attention_f16.o" if t else "attention_bf16.o") for t in (0, 1)] + \
           [("attention_pp.hip", [f"-DUR_TU_F16={t}"], "attention_pp_f16.o" if t else "attention_pp_bf16.o") for t in (0, 1)] + \
           [("attention512.hip", [f"-DUR_TU_F16={t}"], "attention512_f16.o" if t else "attention512_bf16.o") for t in (0, 1)] + \
@@ -52,7 +53,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, oname)
         cmd = [cc, *FLAGS, *EXTRA, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "unirestore_hip.h")]
-        if src.startswith("igemm"):
+        if src.startswith("igemm") or src.startswith("conv_wstream"):
             deps += [os.path.join(CSRC, "igemm_impl.h"), os.path.join(CSRC, "igemm_asm.inc")]
         if src.startswith("attention"):
             deps += [os.path.join(CSRC, "attention_params.h"), os.path.join(CSRC, "attention_pp_asm.inc")]

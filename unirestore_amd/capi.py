@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
         ("nbatch", C.c_int),
         ("bs_x", C.c_longlong), ("bs_x2", C.c_longlong), ("bs_w", C.c_longlong), ("bs_bias", C.c_longlong),
         ("bs_y", C.c_longlong), ("bs_r", C.c_longlong), ("k_chunk_major", C.c_int), ("bias_img_stride", C.c_longlong),
-        ("dtype", C.c_int),
+        ("dtype", C.c_int), ("w_frag", C.c_void_p),
     ]
 
 

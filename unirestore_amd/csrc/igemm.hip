@@ -81,6 +81,9 @@ static inline int himg_16x16(void* kp, hipStream_t s) { return static_cast<ConvK
 int himg_8x8x4_bf16(void* kp, hipStream_t s);
 int himg_8x8x4_f16(void* kp, hipStream_t s);
 static inline int himg_8x8x4(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? himg_8x8x4_f16(kp, s) : himg_8x8x4_bf16(kp, s); }
+int wstream_8x8_bf16(void* kp, hipStream_t s);
+int wstream_8x8_f16(void* kp, hipStream_t s);
+static inline int wstream_8x8(void* kp, hipStream_t s) { return static_cast<ConvK*>(kp)->f16 ? wstream_8x8_f16(kp, s) : wstream_8x8_bf16(kp, s); }
 #ifdef UR_AB_VARIANTS
 int g1_ab_bf16(void* kp, hipStream_t s, int id);
 #endif
@@ -116,6 +119,11 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
   static const bool no_himg = getenv("UR_IGEMM_NOHIMG") != nullptr;
   if (!no_himg && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && k.staged_ok_ && !pair && k.nbatch == 1 && !k.ups &&
       k.OH == k.H && k.OW == k.W && !k.yt && k.Cout % 128 == 0 && k.nk >= 36) {
+    // 8 x 8 maps of a few images: a weight stream (csrc/conv_wstream.hip) when the caller packed the fragment-major copy
+    static const bool no_wstream = getenv("UR_IGEMM_NOWSTREAM") != nullptr;
+    if (!no_wstream && k.wf && k.OH == 8 && k.OW == 8 && k.N <= 16 && k.Cin % 256 == 0 && k.nk >= 72 && k.y && k.ws && !k.gn_ab && !k.row_stats && !k.ln_stats &&
+        (long long)(k.nk / 36) * k.M * k.Cout * 4 <= (long long)k.ws_bytes_)
+      return urk::wstream_8x8(&k, s);
     if (k.OH == 16 && k.OW == 16) return urk::himg_16x16(&k, s);
     if (k.OH == 8 && k.OW == 8 && k.N % 4 == 0) {
       return urk::himg_8x8x4(&k, s);
@@ -231,7 +239,7 @@ static int conv_impl(const ur_conv_desc* d, ur_stream_t stream, int dry, ur_conv
                  (long long)d->Cout * d->ldw < (1ll << 31), "tensor too large for 32-bit element offsets");
   { const char* e = getenv("UR_IGEMM_DBG"); k.dbg = e ? atoi(e) : 0; }
 
-  k.kcm = d->k_chunk_major;
+  k.kcm = d->k_chunk_major; k.wf = (const uint16_t*)d->w_frag;
   UR_REQUIRE(!k.kcm || (k.Cin % 64 == 0 && d->C1 % 64 == 0), "k_chunk_major needs C1 and C1+C2 to be multiples of 64");
   k.gn_part = d->gn_part; k.gn_ab = d->gn_ab; k.gn_silu = d->gn_silu; k.f16 = d->dtype == UR_DT_F16; k.gn_fused = 0; k.gn_parts = 0; k.prologue_ok = 0;
   k.dry = dry; k.plan_tn = 0; k.ln_parts = d->ln_parts;

@@ -102,6 +102,22 @@ class PackedConv:
     ln_colsum: Optional[torch.Tensor] = None   # LayerNorm-fused GEMM: fp32 [cout] row sums of the folded bf16 weight
     ln_eps: float = 0.0
     kcm: bool = False  # K order (64-ch chunk, tap, ch) instead of (tap, ch): consecutive K tiles re-read the same pixels (L2)
+    w_frag: Optional[torch.Tensor] = None      # MFMA-fragment-major copy for the weight-streaming kernel (built on first use)
+
+    def frag(self) -> torch.Tensor:
+        """ur_conv_desc.w_frag: [Cout/128][Cin/64][tap][k-step][row block][lane][8] from the chunk-major rows (csrc/conv_wstream.hip)."""
+        if self.w_frag is None:
+            nt, nc = self.cout // 128, self.cin // 64
+            w = self.w.view(nt, 4, 32, nc, 9, 4, 2, 8)                    # [nt][row block][row][chunk][tap][k-step][half][8]
+            self.w_frag = w.permute(0, 3, 4, 5, 1, 6, 2, 7).contiguous()  # lane = half * 32 + row
+        return self.w_frag
+
+
+def wants_frag(pc: "PackedConv", n, h, w_, c1, c2, stride, upsample, groups) -> bool:
+    """The launches csrc/igemm.hip sends to the weight-streaming kernel (it also checks): 3x3 on 8 x 8 maps of <= 16 images."""
+    return (pc.k == 3 and pc.kcm and groups == 1 and stride == 1 and not upsample and h == 8 and w_ == 8 and n <= 16 and not pc.pair
+            and pc.cout % 128 == 0 and (c1 + c2) % 256 == 0 and (c1 + c2) >= 512 and (c2 == 0 or c1 % 64 == 0)
+            and os.environ.get("UR_IGEMM_NOWSTREAM") is None)
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=False, groups=1, cin_pad=None, c1=None, group_halo=False) -> PackedConv:
@@ -199,6 +215,8 @@ def conv(x: torch.Tensor, pc: PackedConv, *, x2=None, residual=None, bias=None, 
     d.n_split, d.t_rows = n_split, t_rows
     d.k_chunk_major = int(pc.kcm and (c2 == 0 or c1 % 64 == 0))
     assert not pc.kcm or d.k_chunk_major, "chunk-major weights need a 64-aligned concat boundary"
+    if wants_frag(pc, n, h, w_, c1, c2, stride, upsample, g) and pad == (1, 1):
+        d.w_frag = pc.frag().data_ptr()
     d.t_ld = yt.shape[-1] if yt is not None else 0
     d.out_scale = out_scale
     d.nbatch = g
@@ -256,6 +274,8 @@ def conv_plan(x: torch.Tensor, pc: PackedConv, *, x2=None, stride=1, pad=None, u
     d.stride, d.pad_t, d.pad_l, d.OH, d.OW = stride, pad[0], pad[1], oh, ow
     d.upsample2x, d.act, d.out_scale, d.nbatch = int(upsample), act, 1.0, g
     d.k_chunk_major = int(pc.kcm and (c2 == 0 or c1 % 64 == 0))
+    if wants_frag(pc, n, h, w_, c1, c2, stride, upsample, g) and pad == (1, 1):
+        d.w_frag = 16
     if g > 1:
         d.bs_x, d.bs_w, d.bs_bias, d.bs_y, d.bs_r = c1 // g, (pc.cout // g) * pc.w.shape[1], pc.cout // g, pc.cout_out // g, pc.cout_out // g
     plan = ConvPlan()
