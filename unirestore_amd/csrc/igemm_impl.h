@@ -2019,287 +2019,6 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// PERSISTENT form of igemm_halo_ws_kernel (round 6) for launches with several tiles per CU - the VAE, TFA and schedule-batched
-// Controller convs (Cout <= 512 on 128 x 128 ... 512 x 512 maps: 8 - 32 tiles per CU).  Workgroup time lines of the kernel above
-// (tools/halo_wg_timeline.py, profiles/r6_c_timelines.txt) on 128 -> 128 @512x512: 6.1 us prologue + 16.7 us K loop + 7.1 us
-// epilogue per tile, one workgroup per CU (147 KB of LDS) - the matrix pipe idles 44 % of every tile (28 % at 256 -> 256 @256x256).
-// Here gridDim.x workgroups walk the tile list (tile = blockIdx.x + j * gridDim.x through the same XCD-aware map) and the loader
-// wave's piece stream simply RUNS ON across the tile boundary: where the kernel above re-fetches a clamped dummy tile / patch behind
-// the last chunk, this one fetches the NEXT tile's weight tiles 0, 1 and chunk-0 patch - so when the compute waves come back from
-// the epilogue everything their first tap reads is already in LDS (and, with the fused GroupNorm, already normalised but for the
-// pieces of the last half-taps, exactly as between two chunks of one tile).  The epilogue runs in two 128-row halves staged through
-// the patch buffer the finished tile no longer needs (the other one holds the next tile's patch, the ring its weight tiles); its
-// write-through stores drain under the next tile's MFMAs.  The loader takes part in the epilogue's barriers and tile copies.
-template <int TH, int BN, int WM, int WN, bool F16, bool GNP>
-__global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_pws_kernel(const ConvK p) {
-  constexpr int NW = WM * WN, TW = 32, BM = TH * TW, PW = TW + 2, HPIX = (TH + 2) * PW;
-  constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW), HNEED = (HPIX + 7) / 8;
-  constexpr int HPIECES = HSLOTS * NW, HBYTES = HPIECES * 1024;
-  constexpr int HPER = (HNEED + 15) / 16, HTAP = 2 * HPER;
-  constexpr int WBYTES = BN * 128, WPIECES = BN / 8, WH = WPIECES / 2;
-  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = NW * 64;
-  constexpr int BMH = BM / 2;                             // rows of one epilogue half
-  static_assert(NW == 8 && WM == 4 && TH == 8 && WTM % 32 == 0 && WTN % 32 == 0 && HTAP <= NW && ktile_asm_ok<FM, FN>(), "wave layout");
-  static_assert(epi_lds_bytes<BMH, BN, NT>() <= HBYTES, "an epilogue half must fit one patch buffer");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const hbuf = smem;                      // 2 halo patches
-  unsigned char* const wring = smem + 2 * HBYTES;        // 3 weight tiles
-  unsigned char* const abuf = wring + 3 * WBYTES;        // 2 x 1 KiB GroupNorm affine tables
-  constexpr bool gnp = GNP;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
-  const int ntiles = p.tiles_m * p.tiles_n, G = gridDim.x;
-  const int T = (ntiles - (int)blockIdx.x + G - 1) / G;   // tiles of this workgroup (>= 1: the host launches <= ntiles workgroups)
-  const int tiles_x = p.OW / TW, tiles_y = p.OH / TH;
-  const int nchunk = p.nk / 9, nk = nchunk * 9;
-  struct Tile { int tn, tx, ty, img, n0, m0; };
-  auto tile_of = [&](int j) -> Tile {                     // j-th tile of this workgroup (gridDim.x % 8 == 0: the XCD of a tile = the workgroup's)
-    int id = (int)blockIdx.x + min(j, T - 1) * G;
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    Tile t;
-    t.tn = id % p.tiles_n;
-    const int tmi = id / p.tiles_n;
-    t.tx = tmi % tiles_x; t.ty = (tmi / tiles_x) % tiles_y; t.img = tmi / (tiles_x * tiles_y);
-    t.n0 = t.tn * BN;
-    t.m0 = t.img * p.OHW + t.ty * TH * p.OW + t.tx * TW;
-    return t;
-  };
-  const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring, hbuf_lds = (unsigned)(uintptr_t)(lptr_t)hbuf;
-  const unsigned abuf_lds = (unsigned)(uintptr_t)(lptr_t)abuf;
-  const int lr = lane >> 3, ps = lane & 7;
-  auto halo_pixel = [&](const Tile& t, int hr) -> int {  // halo row hr of t's patch -> this lane's input pixel (-1: zero padding / surplus row)
-    const int hy = hr / PW, hx = hr - hy * PW;
-    int iy = t.ty * TH - 1 + hy, ix = t.tx * TW - 1 + hx;
-    const bool v = hr < HPIX && (unsigned)iy < (unsigned)p.OH && (unsigned)ix < (unsigned)p.OW;
-    if (p.ups) { iy >>= 1; ix >>= 1; }
-    return v ? (t.img * p.H + iy) * p.W + ix : -1;
-  };
-  // the two halves of a tile's epilogue, staged through patch buffer `par` (dead: the tile's last chunk); every wave of the workgroup
-  // (the loader takes part in the barriers only: with m0 = M every row of its share is masked, so it issues no load or store - its
-  //  write-through stores would sit in front of the next tile's counted vmcnt and stall the first barrier until they drain)
-  auto epilogue = [&](f32x16 (&acc)[FN][FM], const Tile& t, int par, int wm, int wn, bool compute) {
-    unsigned char* stage = hbuf + par * HBYTES;
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-      igemm_epilogue<FM, FN, WTM, WTN, BMH, BN, NT, F16, false>(p, acc, compute ? t.m0 + h * (TH / 2) * p.OW : p.M, t.n0, wm & 1, wn, lane, 0, 0, stage,
-                                                                compute && (wm >> 1) == h);
-      __syncthreads();                                    // the staged half has left LDS (next half / next tile's patch prefetch overwrite it)
-    }
-  };
-
-  if (wid_s == NW) {
-    // ================================================= loader wave ==================================================
-    const unsigned ck0 = (ps ^ ((lr >> 1) & 7)) * 16u, ck1 = (ps ^ ((4 + (lr >> 1)) & 7)) * 16u;
-    const ig_u32x4 rs_w = ig_make_rsrc(p.w, (unsigned long long)p.Cout * p.ldw * 2);
-    const ig_u32x4 rs_x1 = ig_make_rsrc(p.x, (unsigned long long)p.N * p.H * p.W * p.ldx * 2);
-    const ig_u32x4 rs_x2 = ig_make_rsrc(p.x2 ? p.x2 : p.x, (unsigned long long)p.N * p.H * p.W * (p.x2 ? p.ldx2 : p.ldx) * 2);
-    const ig_u32x4 rs_ab = ig_make_rsrc(gnp ? (const void*)p.gn_ab : (const void*)p.w, gnp ? (unsigned long long)p.N * 2 * p.Cin * 4 : 16ull);
-    Tile cur = tile_of(0), nxt = tile_of(1);
-    unsigned wvo[WPIECES], wvo_n[WPIECES];               // this / the next tile's weight rows (they differ when tiles_n > 1)
-    int hpx[HNEED], hpx_n[HNEED];                         // this / the next tile's pixel table
-    auto weight_rows = [&](const Tile& t, unsigned (&o)[WPIECES]) {
-#pragma unroll
-      for (int q = 0; q < WPIECES; ++q) {
-        const int row = t.n0 + q * 8 + lr;
-        o[q] = row < p.Cout ? (unsigned)row * (unsigned)p.ldw * 2u + ((q & 1) ? ck1 : ck0) : IG_OOB;
-      }
-    };
-    weight_rows(cur, wvo);
-    weight_rows(nxt, wvo_n);
-    f32x16 acc_dummy[FN][FM];                             // (never read: the loader is not an owner in the epilogue)
-    // flat stream position = (tile j, K tile kt): weight tile kt of tile j if kt < nk, else tile kt - nk of tile j + 1 (clamped
-    // to a re-fetch of this tile's last one behind the workgroup's last tile)
-    auto dma_w = [&](bool has_next, int kt, int ring, int q0, int q1) {
-      const bool over = kt >= nk;
-      const bool use_n = over && has_next;
-      const unsigned so = (unsigned)(over ? (has_next ? kt - nk : nk - 1) : kt) * 128u;
-#pragma unroll
-      for (int q = q0; q < q1; ++q) ig_lds_dma16(wring_lds + ring * WBYTES + q * 1024, use_n ? wvo_n[q] : wvo[q], rs_w, so);
-    };
-    auto dma_h = [&](bool has_next, int c, int par, int h) {   // patch pieces of half-tap h of chunk c (c == nchunk: the next tile's chunk 0) -> buffer par
-      const bool over = c >= nchunk;
-      const bool use_n = over && has_next;
-      const int cb = (over ? (has_next ? 0 : nchunk - 1) : c) * 64;
-      const bool second = cb >= p.C1;
-      const unsigned ld2 = (unsigned)(second ? p.ldx2 : p.ldx) * 2u;
-      const unsigned so = (unsigned)(second ? cb - p.C1 : cb) * 2u;
-#pragma unroll
-      for (int j = 0; j < HPER; ++j) {
-        const int q = h * HPER + j;
-        if (h < 16 && q < HNEED) {
-          const int px = use_n ? hpx_n[q] : hpx[q];
-          const unsigned vo = px >= 0 ? (unsigned)px * ld2 + ((q & 1) ? ck1 : ck0) : IG_OOB;
-          const unsigned m0v = hbuf_lds + par * HBYTES + q * 1024;
-          if (second) ig_lds_dma16(m0v, vo, rs_x2, so);
-          else ig_lds_dma16(m0v, vo, rs_x1, so);
-        }
-      }
-    };
-    auto halo_count = [](int h) -> int { return (h >= 16 || h * HPER >= HNEED) ? 0 : (HNEED - h * HPER < HPER ? HNEED - h * HPER : HPER); };
-    auto dma_ab = [&](bool has_next, int c, int par) {     // affine table of chunk c (c == nchunk: the next tile's image, chunk 0)
-      const bool over = c >= nchunk;
-      const int img = (over && has_next) ? nxt.img : cur.img;
-      const unsigned vo = lane < 32 ? (unsigned)((img * 2 + (lane >> 4 & 1)) * p.Cin + (lane & 15) * 4) * 4u : IG_OOB;
-      ig_lds_dma16(abuf_lds + par * 1024, vo, rs_ab, (unsigned)((over ? (has_next ? 0 : nchunk - 1) : c) * 64) * 4u);
-    };
-    // Prologue (first tile only): as in the kernel above
-    if (gnp) dma_ab(false, 0, 0);
-    dma_w(false, 1, 1, 0, WPIECES);
-#pragma unroll
-    for (int q = 0; q < HNEED; ++q) hpx[q] = halo_pixel(cur, q * 8 + lr);
-    if (gnp) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPIECES) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if (gnp) __builtin_amdgcn_s_barrier();
-    int par0 = 0;                                         // patch buffer of the tile's chunk 0
-    for (int j = 0; j < T; ++j) {
-      const bool has_next = j + 1 < T;
-      for (int c = 0; c < nchunk; ++c) {
-        const int parn = (par0 + c + 1) & 1;              // buffer of the stream's next chunk
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int kt = c * 9 + tap;
-          const bool last = kt + 1 == nk && !has_next;    // the workgroup's very last tap
-          dma_w(has_next, kt + 2, (tap + 2) % 3, 0, WH);
-          dma_h(has_next, c + 1, parn, 2 * tap);
-          if (gnp && tap == 0) dma_ab(has_next, c + 1, parn);
-          if (c == 0 && has_next) {                       // the next tile's pixel table, six entries per tap of this tile's first chunk
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-              if (tap * 6 + i < HNEED) hpx_n[tap * 6 + i] = halo_pixel(nxt, (tap * 6 + i) * 8 + lr);
-          }
-          if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WH + halo_count(2 * tap) + ((gnp && tap == 0) ? 1 : 0)) : "memory");
-          __builtin_amdgcn_s_barrier();
-          if (!last) { dma_w(has_next, kt + 2, (tap + 2) % 3, WH, WPIECES); dma_h(has_next, c + 1, parn, 2 * tap + 1); }
-          __builtin_amdgcn_s_barrier();
-        }
-      }
-      epilogue(acc_dummy, cur, (par0 + nchunk - 1) & 1, 0, 0, false);
-      par0 = (par0 + nchunk) & 1;
-      cur = nxt;
-      nxt = tile_of(j + 2);
-#pragma unroll
-      for (int q = 0; q < HNEED; ++q) hpx[q] = hpx_n[q];
-#pragma unroll
-      for (int q = 0; q < WPIECES; ++q) wvo[q] = wvo_n[q];
-      weight_rows(nxt, wvo_n);
-    }
-    return;
-  }
-
-  // =================================================== compute waves ==================================================
-  const int wm = wid % WM, wn = wid / WM;
-  const int chunk = ps ^ ((((wid & 1) << 2) + (lr >> 1)) & 7);
-  static_assert(HTAP % 2 == 0, "piece parity");
-  Tile cur = tile_of(0), nxt = tile_of(1);
-  int hpix[8], hpix_n[8];                                 // this wave's patch pieces (GroupNorm pass; prologue fetch of the first tile)
-  auto pieces_of = [&](const Tile& t, int (&o)[8]) {
-#pragma unroll
-    for (int t8 = 0; t8 < 8; ++t8) o[t8] = (wid < HTAP && t8 * HTAP + wid < HNEED) ? halo_pixel(t, (t8 * HTAP + wid) * 8 + lr) : -1;
-  };
-  pieces_of(cur, hpix);
-  if (gnp) pieces_of(nxt, hpix_n);
-  {
-    // prologue fetch of the first tile: patch 0 and weight tile 0 (see the kernel above)
-    const ig_u32x4 rs_w = ig_make_rsrc(p.w, (unsigned long long)p.Cout * p.ldw * 2);
-    const bool second = 0 >= p.C1;
-    const ig_u32x4 rs_x = second ? ig_make_rsrc(p.x2, (unsigned long long)p.N * p.H * p.W * p.ldx2 * 2) : ig_make_rsrc(p.x, (unsigned long long)p.N * p.H * p.W * p.ldx * 2);
-    const unsigned ld2 = (unsigned)(second ? p.ldx2 : p.ldx) * 2u;
-    if (wid_s < HTAP) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        if (t * HTAP + wid_s < HNEED)
-          ig_lds_dma16(hbuf_lds + (t * HTAP + wid_s) * 1024, hpix[t] >= 0 ? (unsigned)hpix[t] * ld2 + chunk * 16u : IG_OOB, rs_x, 0u);
-    }
-#pragma unroll
-    for (int j = 0; j < (WPIECES + NW - 1) / NW; ++j) {
-      const int q = wid_s + NW * j;
-      if (q < WPIECES) {
-        const int row = cur.n0 + q * 8 + lr;
-        ig_lds_dma16(wring_lds + q * 1024, row < p.Cout ? (unsigned)row * (unsigned)p.ldw * 2u + chunk * 16u : IG_OOB, rs_w, 0u);
-      }
-    }
-  }
-  // this wave's piece of the ones issued in tap t for the patch in buffer par (pieces of tile `next ? nxt : cur`)
-  auto gn_slot = [&](int par, int t, bool next) {
-    const int px = next ? hpix_n[t] : hpix[t];
-    if (px >= 0)
-      gn_piece_inplace<F16>(hbuf + par * HBYTES + (t * HTAP + wid) * 1024 + lane * 16, gn_load_ab(abuf + par * 1024, chunk), p.gn_silu != 0);
-  };
-  const int frow = lane & 31, fhalf = lane >> 5;
-  const unsigned aw_lds = wring_lds + (wn * WTN + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
-  static_assert(((WTN >> 1) & 7) == 0, "the wave's weight rows must keep the swizzle phase of fragment row 0");
-  auto tap_addr = [&](int par, int tp, unsigned (&ab)[FM]) -> unsigned {
-    const int dy = tp / 3, dx = tp % 3;
-#pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      const int hrow = (wm * FM + b + dy) * PW + dx + frow;
-      ab[b] = hbuf_lds + par * HBYTES + hrow * 128 + ((fhalf ^ ((hrow >> 1) & 7)) << 4);
-    }
-    return aw_lds + (tp % 3) * WBYTES;
-  };
-  KPipeRings<FM, FN> rings;
-  kpipe_init(rings);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of patch 0 / weight tile 0
-  __builtin_amdgcn_s_barrier();
-  if (gnp) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) gn_slot(0, t, false);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  int par0 = 0;
-  for (int j = 0; j < T; ++j) {
-    const bool has_next = j + 1 < T;
-    f32x16 acc[FN][FM];
-#pragma unroll
-    for (int a = 0; a < FN; ++a)
-#pragma unroll
-      for (int b = 0; b < FM; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    {
-      unsigned ab0[FM];
-      const unsigned aw0 = tap_addr(par0, 0, ab0);
-      kpipe<FM, FN, F16, 0>(acc, rings, ab0, aw0, ab0, aw0);
-    }
-    for (int c = 0; c < nchunk; ++c) {
-      const int par = (par0 + c) & 1, parn = par ^ 1;
-      const bool last_chunk = c + 1 == nchunk;
-      const bool next_chunk = !last_chunk || has_next;    // the stream goes on: another chunk of this tile, or the next tile's first
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        // pieces issued two taps ago (published by the previous tap's barriers) are normalised next to this tap's MFMAs; tap 0: the
-        // ones of tap 7 of the previous chunk - this chunk's own patch, first read by its tap 6 (for the first chunk of a later
-        // tile: issued in the previous tile's last chunk)
-        if (gnp && tap >= 2 && next_chunk) gn_slot(parn, tap >= 2 ? tap - 2 : 0, last_chunk);
-        if (gnp && tap == 0 && (c > 0 || j > 0)) gn_slot(par, 7, false);
-        unsigned ab[FM], abn[FM];
-        const unsigned aw = tap_addr(par, tap, ab), awn = tap_addr(tap == 8 ? parn : par, (tap + 1) % 9, abn);
-        kpipe<FM, FN, F16, 1>(acc, rings, ab, aw, abn, awn);
-        __builtin_amdgcn_s_barrier();
-        kpipe<FM, FN, F16, 2>(acc, rings, ab, aw, abn, awn);
-        __builtin_amdgcn_s_barrier();
-      }
-    }
-    kpipe_drain(rings);
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // last MFMA of the asm tap body -> VALU reads of the accumulators
-    epilogue(acc, cur, (par0 + nchunk - 1) & 1, wm, wn, true);
-    par0 = (par0 + nchunk) & 1;
-    cur = nxt;
-    nxt = tile_of(j + 2);
-    if (gnp) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) hpix[t] = hpix_n[t];
-      pieces_of(nxt, hpix_n);
-    }
-  }
-}
-
 // Thin-N halo launch (round 5): 3x3 convolutions onto <= 32 output channels - the three conv_out layers (VAE decoder 128 -> 3 at 512 x 512:
 // 747 us at 52 TF/s on the generic 256 x 32 kernel, which gathers every pixel nine times; UNet 320 -> 4; VAE encoder 512 -> 8).  Same
 // patch-in-LDS loader as every halo conv (self-loading kernel: with one weight piece per wave and tap there is nothing for a loader wave to
@@ -2350,33 +2069,17 @@ int launch_halo(ConvK& k, hipStream_t s) {
   const int cps = (nchunk + splitk - 1) / splitk;
   k.splitk = (nchunk + cps - 1) / cps;
   k.nk_per_split = cps * 9;
-  // several tiles per CU: the persistent kernel (256 workgroups walk the tile list, the loader prefetches across the tile boundary,
-  // the epilogue runs in two 128-row halves -> two GroupNorm partials per patch)
-  static const bool no_pws = getenv("UR_HALO_NOPWS") != nullptr;
-  bool pws = false;
-  if constexpr (TH == 8 && BN == 128 && WM == 4) pws = !no_pws && k.splitk == 1 && tiles >= 512 && nchunk >= 2 && !k.row_stats && !k.ln_stats && k.staged_ok_;
-  set_gn_plan(k, true, (pws ? 2 : 1) * (k.OH / TH) * (k.OW / 32));         // a patch never leaves its image: one partial per patch (half)
+  set_gn_plan(k, true, (k.OH / TH) * (k.OW / 32));         // a patch never leaves its image: one partial per patch
   if (k.dry) { k.plan_tn = k.splitk > 1 ? 1 : k.tiles_n; return UR_OK; }
   k.patch_tw = 32;
   static ur::DeviceOnce attr_once;      // the attribute is per device
   if (auto once_guard = attr_once.first()) {
-    if constexpr (TH == 8 && BN == 128 && WM == 4) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_pws_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_pws_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    }
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_ws_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_ws_kernel<TH, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   static const bool no_ws = getenv("UR_HALO_NOWS") != nullptr;          // A/B: every wave loads for itself (rounds 1-2 structure)
-  if constexpr (TH == 8 && BN == 128 && WM == 4) {
-    if (pws) {
-      if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_pws_kernel<TH, BN, WM, WN, F16, GN_OK>), dim3(256), dim3((NW + 1) * 64), lds, s, k));
-      else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_pws_kernel<TH, BN, WM, WN, F16, false>), dim3(256), dim3((NW + 1) * 64), lds, s, k));
-      return ur::check_launch("ur_conv2d_nhwc");
-    }
-  }
   if (no_ws) {
     if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
     else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
