@@ -455,9 +455,10 @@ def test_conv_fused_groupnorm_stats(ops, n, cin, cout, h, w, k):
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,ups,res", [(2, 64, 128, 16, 32, False, False), (1, 320, 320, 32, 32, False, True),
-                                                    (8, 128, 160, 8, 64, False, False), (2, 192, 256, 8, 16, True, True)])
+                                                    (8, 128, 160, 8, 64, False, False), (2, 192, 256, 8, 16, True, True),
+                                                    (3, 256, 128, 8, 8, True, False), (8, 640, 1280, 8, 8, True, True)])   # 8x8 -> 16x16: whole-image tile, chunk-split
 def test_conv_halo_tile_path(ops, n, cin, cout, h, w, ups, res):
-    """3x3 / stride 1 / pad 1 shapes that take the LDS halo-tile kernel (8x32 output patches), incl. fused upsample."""
+    """3x3 / stride 1 / pad 1 shapes that take the LDS halo-tile kernels (8x32 output patches; whole 16x16 images), incl. fused upsample."""
     g = _gen(cin + cout + h)
     x = _rb(torch.randn(n, cin, h, w, generator=g)); wt = _rb(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
     b = torch.randn(cout, generator=g)

@@ -117,8 +117,11 @@ int dispatch_conv(ConvK& k, hipStream_t s, bool pair) {
       !k.bias_img && (long long)k.N * (k.OH / 8) * (k.OW / 32) >= 128)
     return urk::halo_thin_32(&k, s);
   static const bool no_himg = getenv("UR_IGEMM_NOHIMG") != nullptr;
-  if (!no_himg && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && k.staged_ok_ && !pair && k.nbatch == 1 && !k.ups &&
-      k.OH == k.H && k.OW == k.W && !k.yt && k.Cout % 128 == 0 && k.nk >= 36) {
+  static const bool no_himg_ups = getenv("UR_IGEMM_NOHIMGUPS") != nullptr;
+  // (round 6: the 8 x 8 -> 16 x 16 upsampling conv runs on the whole-image tile too - the patch pieces read their nearest source pixel)
+  const bool himg_ups = !no_himg_ups && k.ups && k.OH == 16 && k.OW == 16 && k.H == 8 && k.W == 8;
+  if (!no_himg && k.KH == 3 && k.stride == 1 && k.pad_t == 1 && k.pad_l == 1 && k.kcm && k.staged_ok_ && !pair && k.nbatch == 1 &&
+      ((!k.ups && k.OH == k.H && k.OW == k.W) || himg_ups) && !k.yt && k.Cout % 128 == 0 && k.nk >= 36) {
     // 8 x 8 maps of a few images: a weight stream (csrc/conv_wstream.hip) when the caller packed the fragment-major copy
     static const bool no_wstream = getenv("UR_IGEMM_NOWSTREAM") != nullptr;
     if (!no_wstream && k.wf && k.OH == 8 && k.OW == 8 && k.N <= 16 && k.Cin % 256 == 0 && k.nk >= 72 && k.y && k.ws && !k.gn_ab && !k.row_stats && !k.ln_stats &&
@@ -239,7 +242,7 @@ static int conv_impl(const ur_conv_desc* d, ur_stream_t stream, int dry, ur_conv
                  (long long)d->Cout * d->ldw < (1ll << 31), "tensor too large for 32-bit element offsets");
   { const char* e = getenv("UR_IGEMM_DBG"); k.dbg = e ? atoi(e) : 0; }
 
-  k.kcm = d->k_chunk_major; k.wf = (const uint16_t*)d->w_frag;
+  k.kcm = d->k_chunk_major; k.wf = (const uint16_t*)d->w_frag; k.wmajor = 0; k.xgm = 0; k.xbn = 0;
   UR_REQUIRE(!k.kcm || (k.Cin % 64 == 0 && d->C1 % 64 == 0), "k_chunk_major needs C1 and C1+C2 to be multiples of 64");
   k.gn_part = d->gn_part; k.gn_ab = d->gn_ab; k.gn_silu = d->gn_silu; k.f16 = d->dtype == UR_DT_F16; k.gn_fused = 0; k.gn_parts = 0; k.prologue_ok = 0;
   k.dry = dry; k.plan_tn = 0; k.ln_parts = d->ln_parts;

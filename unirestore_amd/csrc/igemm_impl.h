@@ -43,7 +43,47 @@ struct ConvK {
   int patch_tw, patch_m0_unused;   // >0: tile rows are an (BM/patch_tw) x patch_tw pixel patch of one image (halo kernel)
   int kcm;   // 1: K runs (64-channel chunk, tap, channel) - the 9 taps of a chunk are consecutive K tiles (L2 reuse)
   const uint16_t* wf;   // fragment-major copy of w (ur_conv_desc.w_frag) or null
+  int wmajor;           // 1: weight-major XCD map (igemm_halo_img_kernel: 1-D grid; GEMM kernels: an XCD owns a band of columns)
+  int xgm, xbn;         // xgm > 0: 2-D XCD partition of the tile grid (xcd_tile_map): xgm row bands x (8 / xgm) column bands, xbn = tiles_n * xgm / 8
 };
+
+// blockIdx.x -> (row tile, column tile).  Workgroup id runs on XCD id % 8; every XCD has its own L2, so which tiles an XCD owns decides
+// how often the operands cross the fabric: with xgm row bands x (8 / xgm) column bands the weights are fetched by xgm L2s and the
+// activations by 8 / xgm (pick_xcd_grid chooses per launch).  xgm == 0: the rounds-1-5 map - a contiguous run of tiles per XCD, column
+// tile fastest (= 8 row bands, no divisibility needed), or, wmajor, row tile fastest (= 8 column bands).
+__device__ __forceinline__ void xcd_tile_map(const ConvK& p, int id, int& tm, int& tn) {
+  const int xcd = id & 7, idx = id >> 3;
+  if (p.xgm) {
+    const int lm = idx / p.xbn, ln = idx - lm * p.xbn;
+    tm = (xcd % p.xgm) * (p.tiles_m / p.xgm) + lm;
+    tn = (xcd / p.xgm) * p.xbn + ln;
+    return;
+  }
+  const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7;
+  id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  if (p.wmajor) { tn = id / p.tiles_m; tm = id - tn * p.tiles_m; }
+  else { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; }
+}
+
+// Host: the XCD grid with the least operand traffic through the fabric, gm * W + (8 / gm) * A (W, A = weight / activation elements of
+// the launch), among the shapes the tile grid divides into; kept only when it beats the contiguous-run map (8 * W + A) by >= 10 %.
+// Measured where it matters - the 16x16 / 8x8 levels, whose launches move 2 - 4 TB/s through the fabric with the old map
+// (profiles/r6_pmc_conv.json, profiles/r5_pmc_gemm.json: HBM-side fetch 3.7 - 7.3 x the algorithmic bytes).
+static inline void pick_xcd_grid(ConvK& k, double W, double A) {
+  k.xgm = 0; k.xbn = 0; k.wmajor = 0;
+  static const bool off = getenv("UR_NOXCDGRID") != nullptr;
+  if (off || k.nbatch != 1) return;
+  const long long nt = (long long)k.tiles_m * k.tiles_n;
+  double best = 0.9 * (8.0 * W + A);
+  if (nt % 8 == 0)
+    for (int gm = 4; gm >= 1; gm >>= 1) {
+      const int gn = 8 / gm;
+      if (k.tiles_m % gm || k.tiles_n % gn) continue;
+      const double c = gm * W + gn * A;
+      if (c < best) { best = c; k.xgm = gm; k.xbn = k.tiles_n / gn; }
+    }
+  if (!k.xgm && k.tiles_n >= 8 && W + 8.0 * A < best) k.wmajor = 1;       // ragged grids: contiguous runs, row tile fastest
+}
 
 __device__ __forceinline__ bool is_pair_act(int act) { return act == UR_ACT_GEGLU || act == UR_ACT_GATE; }
 
@@ -530,13 +570,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
   const int wm = wid % WM, wn = wid / WM;
   const int gb = blockIdx.y, sz = blockIdx.z;
 
-  // XCD-aware bijective remap: XCD (id % 8) owns a contiguous run of tiles, n-tile fastest.
-  int id = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+  int tm, tn;
+  xcd_tile_map(p, blockIdx.x, tm, tn);                  // XCD-aware bijective remap
   const int m0 = tm * BM, n0 = tn * BN;
 
   const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
@@ -951,6 +986,7 @@ int launch_cfg(ConvK& k, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, true, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
+  pick_xcd_grid(k, (double)k.Cout * k.Ktot, (double)k.N * k.H * k.W * k.Cin);
   static const bool no_g1 = getenv("UR_IGEMM_NOG1") != nullptr;
   const bool g1 = !no_g1 && k.KH == 1 && k.stride == 1 && !k.ups && k.C2 == 0 && k.pad_t == 0 && k.pad_l == 0 && k.OH == k.H && k.OW == k.W &&
                   (long long)k.M * k.ldx + k.Ktot < (1ll << 31);
@@ -982,12 +1018,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_glds_kernel(const ConvK p) 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid % WM, wn = wid / WM;
   const int gb = blockIdx.y, sz = blockIdx.z;
-  int id = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+  int tm, tn;
+  xcd_tile_map(p, blockIdx.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
@@ -1180,12 +1212,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const ConvK p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid % WM, wn = wid / WM;
   const int gb = blockIdx.y;
-  int id = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+  int tm, tn;
+  xcd_tile_map(p, blockIdx.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const uint16_t* __restrict__ X1 = p.x + gb * p.bs_x;
   const uint16_t* __restrict__ Wt = p.w + gb * p.bs_w;
@@ -1318,6 +1346,7 @@ int launch_gemm(ConvK& k, hipStream_t s) {
   if (auto once_guard = attr_once.first()) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
+  pick_xcd_grid(k, (double)k.Cout * k.Ktot, (double)k.M * k.Cin);
   UR_F16_SWITCH(k, hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NST, DIRECT, PAIRC, F16>), dim3(k.tiles_m * k.tiles_n, k.nbatch, 1), dim3(WM * WN * 64), lds, s, k));
   return ur::check_launch("ur_conv2d_nhwc");
 }
@@ -1345,6 +1374,7 @@ int launch_glds(ConvK& k, hipStream_t s, int min_blocks) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<BM, BN, WM, WN, NST, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   dim3 grid(k.tiles_m * k.tiles_n, k.nbatch, k.splitk);
+  pick_xcd_grid(k, (double)k.Cout * k.Ktot, (double)k.N * k.H * k.W * k.Cin);
   UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_glds_kernel<BM, BN, WM, WN, NST, F16>), grid, dim3(WM * WN * 64), lds, s, k));
   if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
@@ -2120,13 +2150,23 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid % WM, wn = wid / WM;
-  const int sz = blockIdx.y;
-  int id = blockIdx.x;
-  {
+  int sz = blockIdx.y, tn, tmi;
+  if (p.wmajor) {
+    // weight-major XCD map (round 6; 1-D grid, workgroup L runs on XCD L % 8): these layers multiply a few MB of activations with
+    // 15 - 59 MB of weights, so every (channel tile, chunk split) slice of the weights belongs to ONE XCD - its tiles_m image tiles are
+    // consecutive dispatch slots there, the slice leaves HBM / the Infinity Cache once and the other tiles hit that XCD's L2.  The
+    // tile-major map below gave every XCD one image and ALL the weights: 291 MB through the fabric per 1280 -> 1280 @16x16 launch against
+    // 40 MB algorithmic (profiles/r6_pmc_conv.json).
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int g = (j / p.tiles_m) * 8 + xcd;
+    if (g >= p.tiles_n * p.splitk) return;
+    tn = g % p.tiles_n; sz = g / p.tiles_n; tmi = j % p.tiles_m;
+  } else {
+    int id = blockIdx.x;
     const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tn = id % p.tiles_n; tmi = id / p.tiles_n;
   }
-  const int tn = id % p.tiles_n, tmi = id / p.tiles_n;
   const int n0 = tn * BN, img0 = tmi * NIMG, m0 = tmi * BM;
 
   typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -2145,7 +2185,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
     const int im = hr / HP, rin = hr - im * HP, hy = rin / PW, hx = rin - hy * PW;
     const int iy = hy - 1, ix = hx - 1;
     const bool v = hr < HPIX && img0 + im < p.N && (unsigned)iy < (unsigned)TH && (unsigned)ix < (unsigned)TW;
-    hpix[t] = v ? ((img0 + im) * TH + iy) * TW + ix : -1;
+    // fused nearest-2x upsample (p.ups): the patch is TH x TW pixels of the UPSAMPLED image, every piece reads its source pixel
+    const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
+    hpix[t] = v ? ((img0 + im) * p.H + sy) * p.W + sx : -1;
     hchk[t] = ps ^ (((rin >> 1) - hy) & 7);
   }
   const int wchunk = ps ^ ((((wid & 1) << 2) + (lr >> 1)) & 7);      // weight tile keeps the (row>>1)&7 swizzle
@@ -2163,8 +2205,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
   // buffer-descriptor LDS-DMA (ig_lds_dma16): zero border / ragged rows through the descriptor's range check
   const int wid_s = __builtin_amdgcn_readfirstlane(wid);
   const ig_u32x4 rs_w = ig_make_rsrc(Wt, (unsigned long long)p.Cout * p.ldw * 2);
-  const ig_u32x4 rs_x1 = ig_make_rsrc(X1, (unsigned long long)p.N * TH * TW * p.ldx * 2);
-  const ig_u32x4 rs_x2 = ig_make_rsrc(X2 ? X2 : X1, (unsigned long long)p.N * TH * TW * (X2 ? p.ldx2 : p.ldx) * 2);
+  const ig_u32x4 rs_x1 = ig_make_rsrc(X1, (unsigned long long)p.N * p.H * p.W * p.ldx * 2);
+  const ig_u32x4 rs_x2 = ig_make_rsrc(X2 ? X2 : X1, (unsigned long long)p.N * p.H * p.W * (X2 ? p.ldx2 : p.ldx) * 2);
   const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring, hbuf_lds = (unsigned)(uintptr_t)(lptr_t)hbuf;
   unsigned wvo[WPW];
 #pragma unroll
@@ -2331,8 +2373,13 @@ int launch_halo_img(ConvK& k, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0, GN_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
-  if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
-  else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
+  // weight-major XCD map when the weights outweigh the activations and the per-XCD share still fits one round of its 32 CUs
+  static const bool no_wmajor = getenv("UR_HIMG_NOWMAJOR") != nullptr;
+  const int slices = k.tiles_n * k.splitk, per_xcd = ((slices + 7) / 8) * k.tiles_m;
+  k.wmajor = !no_wmajor && (long long)k.Cout * k.Ktot > (long long)k.N * k.H * k.W * k.Cin && per_xcd <= 32 && slices >= 8;
+  const dim3 grid = k.wmajor ? dim3(8 * per_xcd, 1) : dim3(k.tiles_m * k.tiles_n, k.splitk);
+  if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, GN_OK>), grid, dim3(NW * 64), lds, s, k));
+  else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, false>), grid, dim3(NW * 64), lds, s, k));
   if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
 }
