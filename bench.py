@@ -300,7 +300,30 @@ def main():
                               "share_of_forward": round(dom["ms"] / sum(v["ms"] for v in rep.values()), 3)}
         # HBM bytes of the most frequent launch of the conv family (conv3x3 320->320 @64x64, B=8), from separate rocprofv3 --pmc
         # passes (FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE), committed file; null for other families
-        for cand in ("r4_pmc_halo_conv.json", "r3_pmc_halo_conv.json", "r2_pmc_dominant.json", "r2_pmc_halo_conv.json"):
+        r6 = os.path.join(ROOT, "profiles", "r6_pmc_conv.json")
+        if dom_name == "conv3x3_igemm" and os.path.exists(r6):
+            pj = json.load(open(r6))
+            cl = {c["class"]: c for c in pj["classes"]}
+            c0 = cl["unet c3 320->320@64"]
+            k0 = c0["kernels"][0]
+            result["roofline"]["traffic"] = c0["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_algorithmic"] = c0["algorithmic_read_bytes"] + c0["algorithmic_write_bytes"]
+            result["roofline"]["traffic_note"] = (
+                "most frequent conv3x3 launch (320->320 @64x64, B=8: 140 per forward), re-measured this round (profiles/r6_pmc_conv.json, separate "
+                f"--pmc passes, FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE): {c0['hbm_over_algorithmic']} x algorithmic (halo rows re-read by "
+                f"neighbouring 8x32 patches); matrix pipe busy {k0['mfma_busy_frac']:.3f} of the launch's GPU cycles.  HBM-side bytes / algorithmic per "
+                "conv class (same file): " + ", ".join(f"{c['class']} {c['hbm_over_algorithmic']}" for c in pj["classes"]) +
+                ".  The K-loop limiter is not named by a counter: 1226-1242 W of the 1400 W socket cap at 1.58 GHz in-kernel clock (rounds 3-5; the "
+                "virtualised SMI exposes no throttle-reason fields) - recorded as unknown-electrical, not as a measured power cap")
+            result["roofline"]["class_matrix_busy"] = {c["class"]: c["kernels"][0].get("mfma_busy_frac") for c in pj["classes"]}
+            r4 = os.path.join(ROOT, "profiles", "r4_pmc_halo_conv.json")
+            if os.path.exists(r4):
+                ck = json.load(open(r4)).get("k_loop_shader_clock_ghz")
+                if ck:
+                    result["roofline"]["sustained_clock_ghz"] = ck
+                    result["roofline"]["peak_at_sustained_clock"] = round(2500.0 * ck / 2.4, 1)
+        for cand in (() if result["roofline"]["traffic"] is not None else
+                     ("r4_pmc_halo_conv.json", "r3_pmc_halo_conv.json", "r2_pmc_dominant.json", "r2_pmc_halo_conv.json")):
             pmc = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
@@ -313,6 +336,13 @@ def main():
                         result["roofline"]["peak_at_sustained_clock"] = round(2500.0 * pj["k_loop_shader_clock_ghz"] / 2.4, 1)
                     break
         result["families"] = fam
+        # the same families as the REPLAYED GRAPH runs them (rocprofv3 kernel trace of this command, committed with the round's profiles:
+        # the event-wrapped eager pass above reads short launches 40 - 60 % slow)
+        ig = os.path.join(ROOT, "profiles", "r6_in_graph_families.json")
+        if os.path.exists(ig):
+            ij = json.load(open(ig))
+            result["families_in_graph"] = ij["families_in_graph"]
+            result["families_in_graph_source"] = ij["source"]
         result["profiled_forward_ms"] = round(sum(v["ms"] for v in rep.values()), 2)
         # kernel nodes of the captured graph that come from this library (one per launch of the eager pass; torch adds a few copies)
         result["library_launches_per_forward"] = int(sum(v["launches"] for v in rep.values()))
