@@ -88,6 +88,26 @@ def round_up(v, m):
 
 
 # ------------------------------------------------------------------------------------------------ weights
+# A/B (UR_WEIGHT_ARENA=<GiB per block>): packed weights live in a few multi-GiB allocations instead of one allocation each - one UNet
+# step walks 1.7 GB of weights, and how many address translations that costs depends on how the driver can map them.
+_ARENA_GB = float(os.environ.get("UR_WEIGHT_ARENA", "0") or 0)
+_arenas = {}
+
+
+def _arena_place(t: torch.Tensor) -> torch.Tensor:
+    if _ARENA_GB <= 0 or not t.is_cuda:
+        return t
+    nbytes = round_up(t.numel() * t.element_size(), 4096)
+    blocks = _arenas.setdefault(t.device, [])
+    if not blocks or blocks[-1][1] + nbytes > blocks[-1][0].numel():
+        blocks.append([torch.empty(max(int(_ARENA_GB * (1 << 30)), nbytes), dtype=torch.uint8, device=t.device), 0])
+    buf, off = blocks[-1]
+    blocks[-1][1] = off + nbytes
+    v = buf[off:off + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+    v.copy_(t)
+    return v
+
+
 @dataclass
 class PackedConv:
     """16-bit [Cout][KH*KW*Cin] weight (K runs tap-major, channel-minor) + fp32 bias, padded for the kernel."""
@@ -109,7 +129,7 @@ class PackedConv:
         if self.w_frag is None:
             nt, nc = self.cout // 128, self.cin // 64
             w = self.w.view(nt, 4, 32, nc, 9, 4, 2, 8)                    # [nt][row block][row][chunk][tap][k-step][half][8]
-            self.w_frag = w.permute(0, 3, 4, 5, 1, 6, 2, 7).contiguous()  # lane = half * 32 + row
+            self.w_frag = _arena_place(w.permute(0, 3, 4, 5, 1, 6, 2, 7).contiguous())  # lane = half * 32 + row
         return self.w_frag
 
 
@@ -158,7 +178,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dev, *, pair=F
     kcm = kh == 3 and (groups == 1 or (group_halo and cout_p == cout)) and cin_p % 64 == 0 and (c1 is None or c1 % 64 == 0) and os.environ.get("UR_KCM", "1") == "1"
     if kcm:
         wp = wp.reshape(cout_p, kh * kw, cin_p // 64, 64).permute(0, 2, 1, 3)
-    return PackedConv(wp.reshape(cout_p, kh * kw * cin_p).to(_act).contiguous(),
+    return PackedConv(_arena_place(wp.reshape(cout_p, kh * kw * cin_p).to(_act).contiguous()),
                       None if b is None else b.contiguous(), cin_p, cout_p, cout_out, kh, groups, pair, kcm=kcm)
 
 
