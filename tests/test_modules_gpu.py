@@ -49,6 +49,20 @@ def test_csce_golden(M, gdt, name):
     assert rel_l2(m(i["x"], i["condition"]).cpu(), o["y"]) < GTOL[gdt]
 
 
+def test_operator_level_fp16_overflow_is_loud(M, gdt):
+    """Advisor (round 5): the fp16 conversions overflow to inf, and only DiffUIE.forward checked.  An adapter called at operator level with
+    activations beyond the fp16 range must raise too (bf16 has fp32's range and returns finite values)."""
+    w, i, o = load_golden("csce_0")
+    m = M.CSCEAdapter(w["proj.weight"].shape[0], w["tuner.0.weight"].shape[0], w["proj.weight"].shape[1])
+    m.load_state_dict(w)
+    big = i["x"] * 3.0e5                                   # |x| far beyond 65504: s = x + proj(cond) overflows in fp16 storage
+    if gdt == "fp16":
+        with pytest.raises(FloatingPointError):
+            m(big, i["condition"])
+    else:
+        assert bool(torch.isfinite(m(big, i["condition"])).all())
+
+
 @pytest.mark.parametrize("name", golden_names("tfa"))
 def test_tfa_golden(M, gdt, name):
     w, i, o = load_golden(name)

@@ -53,7 +53,11 @@ template <> struct Act<true> {
   static __device__ __forceinline__ float one(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
   // round-to-nearest-even, IEEE overflow: |v| > 65504 becomes +-inf (round 5; rounds 2-4 clamped to +-65504).  A clipped
   // activation is a silently wrong image; an inf reaches the next GroupNorm / softmax as NaN and the caller's finite check
-  // (DiffUIE.forward raises FloatingPointError in fp16) - overflow is loud, and the pack is one instruction like bf16's.
+  // (every public fp16 entry point of unirestore_amd.modules - DiffUIE.forward, Controller.forward, ControlledUNet.forward,
+  // predict_z0, the adapters' operator-level forwards - checks its result and raises FloatingPointError) - overflow is loud, and the pack
+  // is one instruction like bf16's.  NOT every inf survives to an output: -inf in an attention score becomes exp = 0, +-inf in front of the
+  // 8-bit quantiser would clamp to 0 / 1 (the quantiser therefore propagates NaN and the check runs on its input's consumers); callers of
+  // the raw C ABI get IEEE infs / NaNs in their tensors and check for themselves.
   static __device__ __forceinline__ uint32_t pack2(float a, float b) {
     f32x2_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
@@ -179,27 +183,30 @@ int gn_stats_launch(const void* x, float* part, int N, int HW, int C, int dtype,
 // aliasing above 63: one bit vector word per 64 devices).
 struct DeviceOnce {
   std::mutex mu;
-  std::vector<unsigned long long> done;
+  std::atomic<unsigned long long> done[4] = {};           // one bit per device (256 devices): set once the guarded block has run there
   struct Guard {
     std::unique_lock<std::mutex> lk;
-    std::vector<unsigned long long>* done = nullptr;
+    std::atomic<unsigned long long>* word = nullptr;
     int dev = 0;
     bool run = false;
     Guard() = default;
-    Guard(Guard&& o) noexcept : lk(std::move(o.lk)), done(o.done), dev(o.dev), run(o.run) { o.run = false; }
+    Guard(Guard&& o) noexcept : lk(std::move(o.lk)), word(o.word), dev(o.dev), run(o.run) { o.run = false; }
     explicit operator bool() const { return run; }
     ~Guard() {
-      if (run) (*done)[dev >> 6] |= 1ull << (dev & 63);        // still under the lock: waiters see the finished state
+      if (run) word->fetch_or(1ull << (dev & 63), std::memory_order_release);       // still under the lock: waiters see the finished state
     }
   };
+  // Fast path (every launch after the first on a device): one acquire load, no lock - host threads driving different GPUs do not meet.
   Guard first() {
     int dev = 0;
     (void)hipGetDevice(&dev);
     Guard g;
+    std::atomic<unsigned long long>& w = done[(dev >> 6) & 3];
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (w.load(std::memory_order_acquire) & bit) return g;
     g.lk = std::unique_lock<std::mutex>(mu);
-    if ((size_t)(dev >> 6) >= done.size()) done.resize((dev >> 6) + 1, 0ull);
-    g.run = !(done[dev >> 6] >> (dev & 63) & 1ull);
-    g.done = &done;
+    g.run = !(w.load(std::memory_order_acquire) & bit);
+    g.word = &w;
     g.dev = dev;
     if (!g.run) g.lk.unlock();
     return g;

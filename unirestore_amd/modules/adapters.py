@@ -24,6 +24,13 @@ def _named(**mods):
     return nn.ModuleDict({k.lstrip("_"): v for k, v in mods.items()})
 
 
+def _finite16(t):
+    """Operator-level fp16 entry points check what they return (fp16 conversions overflow to inf: csrc/common.h Act<true>::pack2)."""
+    if ops.act_dtype() == torch.float16 and not bool(torch.isfinite(t).all()):
+        raise FloatingPointError("fp16 activation overflow (|x| > 65504): the result is not finite.  Use dtype='bf16' for these weights")
+    return t
+
+
 def _to_nhwc(x):
     return ops.nchw_to_nhwc(x.to(DEV))
 
@@ -58,7 +65,7 @@ class CSCEAdapter(nn.Module):
 
     def forward(self, x, condition):
         _fresh()
-        return ops.nhwc_to_nchw(self.run(_to_nhwc(x), _to_nhwc(condition)), c=x.shape[1])
+        return _finite16(ops.nhwc_to_nchw(self.run(_to_nhwc(x), _to_nhwc(condition)), c=x.shape[1]))
 
 
 class SPADE(nn.Module):
@@ -95,7 +102,7 @@ class SPADE(nn.Module):
 
     def forward(self, x, segmap):
         _fresh()
-        return ops.nhwc_to_nchw(self.run(_to_nhwc(x), _to_nhwc(segmap)), c=x.shape[1])
+        return _finite16(ops.nhwc_to_nchw(self.run(_to_nhwc(x), _to_nhwc(segmap)), c=x.shape[1]))
 
 
 class LayerNorm2d(LayerNorm):
@@ -155,7 +162,7 @@ class NAFBlock(nn.Module):
 
     def forward(self, inp):
         _fresh()
-        return ops.nhwc_to_nchw(self.run(_to_nhwc(inp)), c=inp.shape[1])
+        return _finite16(ops.nhwc_to_nchw(self.run(_to_nhwc(inp)), c=inp.shape[1]))
 
 
 class AdaNAFV2(nn.Module):
@@ -183,12 +190,13 @@ class AdaNAFV2(nn.Module):
         """The grouped 3x3 conv (16 groups of 4c/16 channels: cfrm.py:20-21).  Groups narrower than a 64-channel halo chunk would
         take the generic batched kernel (a 64-byte gather per pixel and tap: 2.19 ms at 256 x 256 x 512); they are densified instead
         into block-diagonal 128 -> 128 convolutions (zeros outside a group's own block: same sums, 2-4x the MFMA work, all of it
-        at the halo kernel's rate) and run as 4c/128 "groups" of 128 channels."""
+        at the halo kernel's rate) and run as 4c/128 "groups" of 128 channels.  Only for the measured widths (32- and 64-channel
+        groups = the production CFRM): narrower groups would pay 8-16x the MFMA work and weight bytes and stay on the batched kernel."""
         key = ("pk", "gc", ops.act_dtype())
         if key not in self.__dict__:
             gc = self.group_conv
             w, cg, g = gc.weight.detach().float(), gc.weight.shape[1], gc.groups          # [W, Cg, 3, 3]
-            if cg < 128 and w.shape[0] % 128 == 0 and 128 % cg == 0 and os.environ.get("UR_GC_DENSE", "1") == "1":
+            if 32 <= cg < 128 and w.shape[0] % 128 == 0 and 128 % cg == 0 and os.environ.get("UR_GC_DENSE", "1") == "1":
                 wd = torch.zeros(w.shape[0], 128, 3, 3)
                 o = torch.arange(w.shape[0])
                 off = ((o // cg) * cg) % 128                                                 # first input channel of o's group inside its 128-block
@@ -213,7 +221,7 @@ class AdaNAFV2(nn.Module):
 
     def forward(self, inp):
         _fresh()
-        return ops.nhwc_to_nchw(self.run(_to_nhwc(inp)), c=inp.shape[1])
+        return _finite16(ops.nhwc_to_nchw(self.run(_to_nhwc(inp)), c=inp.shape[1]))
 
 
 class _Seq(nn.Sequential):
@@ -224,7 +232,7 @@ class _Seq(nn.Sequential):
 
     def forward(self, x):
         _fresh()
-        return ops.nhwc_to_nchw(self.run(_to_nhwc(x)), c=x.shape[1])
+        return _finite16(ops.nhwc_to_nchw(self.run(_to_nhwc(x)), c=x.shape[1]))
 
 
 def cfrm_blocks(channels=(128, 256, 512), depths=(1, 1, 9)) -> nn.ModuleList:
@@ -290,7 +298,7 @@ class TaskFeatureAdapter(nn.Module):
     def forward(self, x, skip, condition):
         _fresh()
         y, c = self.run(_to_nhwc(x), _to_nhwc(skip), condition.to(DEV).float())
-        return ops.nhwc_to_nchw(y, c=x.shape[1]), c
+        return _finite16(ops.nhwc_to_nchw(y, c=x.shape[1])), c
 
 
 TaskEditorV1c = TaskFeatureAdapter     # the reference imports it under this stale name (autoencoder.py:112)

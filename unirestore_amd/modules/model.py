@@ -40,6 +40,17 @@ def _use_dtype(module):
         ops.set_dtype(dt)
 
 
+def _check_fp16(*tensors):
+    """fp16 conversions overflow to inf (csrc/common.h Act<true>::pack2): every public operator-level entry point checks what it
+    returns, so an fp16 range problem raises instead of handing the caller inf / NaN tensors (bf16 has fp32's range: no check)."""
+    if ops.act_dtype() != torch.float16:
+        return
+    for t in tensors:
+        for v in (t.values() if isinstance(t, dict) else (t,)):
+            if not bool(torch.isfinite(v).all()):
+                raise FloatingPointError("fp16 activation overflow (|x| > 65504): the result is not finite.  Use dtype='bf16' for these weights")
+
+
 def _per_sample_timesteps(timesteps, batch):
     """Reference operator contract (controller.py:193-194, base_model.py:211-216): `timesteps` is a scalar / (1,) tensor shared by
     the batch, or a (B,) tensor with one timestep per sample.  Returns [t] or the B per-sample values (all-equal collapses to [t])."""
@@ -129,7 +140,9 @@ class Controller(nn.Module):
         # one table row per distinct request: a (1,) tensor is row 0 for every image; a (B,) tensor gives image i row i
         # (controller.py:193-194 broadcasts the same way) - the step-major "all" form with one image per row
         out = self.run(self.stem(ops.nchw_to_nhwc(x.to(DEV))), 0 if len(ts) == 1 else "all")
-        return {k: ops.nhwc_to_nchw(v) for k, v in out.items()}
+        out = {k: ops.nhwc_to_nchw(v) for k, v in out.items()}
+        _check_fp16(out)
+        return out
 
 
 class ControlledUNet(nn.Module):
@@ -214,7 +227,9 @@ class ControlledUNet(nn.Module):
         self.set_timesteps(ts)
         ctl = {k: ops.nchw_to_nhwc(v.to(DEV)) for k, v in control.items()}
         eps = self.run(ops.nchw_to_nhwc(sample.to(DEV)), ctl, 0 if len(ts) == 1 else "all")     # (B,) timesteps: image i = bias row i
-        return ops.nhwc_to_nchw(eps, c=self.unet.conv_out.out_channels)
+        eps = ops.nhwc_to_nchw(eps, c=self.unet.conv_out.out_channels)
+        _check_fp16(eps)
+        return eps
 
 
 class SkipConnectedAutoEncoder(nn.Module):
@@ -539,4 +554,6 @@ class DiffUIE(nn.Module):
             eps = ops.nhwc_to_nchw(self.base_model.run(zb[i:i + 1].contiguous(), control, i), c=lat)
             a = float(schedule.alphas_cumprod()[t])
             outs.append((latents[i:i + 1].to(DEV).float() - (1 - a) ** 0.5 * eps) / a ** 0.5)
-        return torch.cat(outs, 0)
+        z0 = torch.cat(outs, 0)
+        _check_fp16(z0)
+        return z0
