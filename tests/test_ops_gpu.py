@@ -651,3 +651,48 @@ def test_conv_halo_wave_specialised_equals_self_loading_kernel(ops, tmp_path):
     assert len(res[0]) == len(res[1]) == 2 * len(cases)
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+_XCD_AB_SNIPPET = r"""
+import sys, math, torch
+sys.path.insert(0, {root!r})
+from unirestore_amd import ops
+ops.set_dtype({dt!r})
+DT = ops.act_dtype()
+outs = []
+for (m, k, n, pair) in {lin!r}:
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g).to(DT); w = (torch.randn(n, k, generator=g) / math.sqrt(k)).to(DT).float(); b = torch.randn(n, generator=g)
+    r = None if pair else torch.randn(m, n, generator=g).to(DT).cuda()
+    y = ops.linear(x.cuda(), ops.pack_conv(w, b, "cuda", pair=pair), residual=r, act=ops.UR_ACT_GEGLU if pair else ops.UR_ACT_NONE)
+    outs.append(y.cpu())
+for (nimg, cin, cout, hw, ups) in {convs!r}:
+    g = torch.Generator().manual_seed(cin + cout + hw)
+    x = torch.randn(nimg, hw, hw, cin, generator=g).to(DT); wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(DT).float()
+    y = ops.conv(x.cuda(), ops.pack_conv(wt, torch.randn(cout, generator=g), "cuda"), upsample=ups, gn=True)
+    outs.append(y.cpu()); outs.append(ops.gn_of(y)[0].cpu())
+torch.save(outs, {out!r})
+"""
+
+
+def test_xcd_tile_grids_change_nothing_but_the_placement(ops, tmp_path):
+    """Round 6: which XCD computes which tile is chosen per launch (pick_xcd_grid: 4 x 2 / 2 x 4 / 1 x 8 XCD grids, the row-tile-fastest
+    fallback on ragged grids, the weight-major 1-D grid of the whole-image halo conv).  The arithmetic of a tile does not depend on where it
+    runs: outputs (and GroupNorm partial planes) must be BIT-identical to the rounds-1-5 map (UR_NOXCDGRID=1 UR_HIMG_NOWMAJOR=1, read once
+    per process: second process) - on the shapes of the 16x16 / 8x8 levels the map was built for, a ragged grid, a multi-round grid."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lin = [(2048, 1280, 3840, False), (512, 1280, 1280, False), (2048, 1280, 10240, True), (512, 1280, 10240, True), (2048, 5120, 1280, False),
+           (2048, 1280, 1280, False), (8192, 640, 640, False), (1000, 328, 1288, False), (4096, 640, 1920, False), (512, 2560, 1280, False)]
+    convs = [(8, 1280, 1280, 16, False), (8, 640, 1280, 16, False), (3, 256, 384, 16, False), (8, 512, 1280, 8, True)]
+    dt = "fp16" if DT == torch.float16 else "bf16"
+    res = []
+    for tag, env in (("grid", {}), ("old", {"UR_NOXCDGRID": "1", "UR_HIMG_NOWMAJOR": "1"})):
+        out = str(tmp_path / f"{tag}.pt")
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _XCD_AB_SNIPPET.format(root=root, dt=dt, lin=lin, convs=convs, out=out)], env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(torch.load(out))
+    assert len(res[0]) == len(res[1]) == len(lin) + 2 * len(convs)
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b), i
