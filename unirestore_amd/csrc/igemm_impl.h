@@ -75,6 +75,11 @@ static inline void pick_xcd_grid(ConvK& k, double W, double A) {
   if (off || k.nbatch != 1) return;
   const long long nt = (long long)k.tiles_m * k.tiles_n;
   double best = 0.9 * (8.0 * W + A);
+  static const int force = getenv("UR_XCD_FORCE") ? atoi(getenv("UR_XCD_FORCE")) : 0;      // A/B: this row-band count wherever the grid divides
+  if (force && nt % 8 == 0 && 8 % force == 0 && k.tiles_m % force == 0 && k.tiles_n % (8 / force) == 0) {
+    if (force < 8) { k.xgm = force; k.xbn = k.tiles_n / (8 / force); }
+    return;
+  }
   if (nt % 8 == 0)
     for (int gm = 4; gm >= 1; gm >>= 1) {
       const int gn = 8 / gm;
