@@ -684,10 +684,13 @@ def test_xcd_tile_grids_change_nothing_but_the_placement(ops, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lin = [(2048, 1280, 3840, False), (512, 1280, 1280, False), (2048, 1280, 10240, True), (512, 1280, 10240, True), (2048, 5120, 1280, False),
            (2048, 1280, 1280, False), (8192, 640, 640, False), (1000, 328, 1288, False), (4096, 640, 1920, False), (512, 2560, 1280, False)]
-    convs = [(8, 1280, 1280, 16, False), (8, 640, 1280, 16, False), (3, 256, 384, 16, False), (8, 512, 1280, 8, True)]
+    convs = [(8, 1280, 1280, 16, False), (8, 640, 1280, 16, False), (3, 256, 384, 16, False), (8, 512, 1280, 8, True),
+             (2, 320, 320, 64, False), (1, 128, 128, 128, False), (4, 512, 512, 8, False), (2, 640, 640, 32, False)]      # 8 x 32 halo tiles (+ chunk split), 8x8x4 tiles
     dt = "fp16" if DT == torch.float16 else "bf16"
     res = []
-    for tag, env in (("grid", {}), ("old", {"UR_NOXCDGRID": "1", "UR_HIMG_NOWMAJOR": "1"})):
+    # (the second process also runs the rounds-3-5 loader structures: ONE loader wave in the 8 x 32 halo conv, the self-loading whole-image
+    #  kernel - the two-loader kernels of round 6 accumulate in the same order)
+    for tag, env in (("grid", {}), ("old", {"UR_NOXCDGRID": "1", "UR_HIMG_NOWMAJOR": "1", "UR_HALO_LD1": "1", "UR_HIMG_NOWS": "1"})):
         out = str(tmp_path / f"{tag}.pt")
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", _XCD_AB_SNIPPET.format(root=root, dt=dt, lin=lin, convs=convs, out=out)], env=e, capture_output=True, text=True)

@@ -1775,7 +1775,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Wave-specialised form of igemm_halo_kernel: NW compute waves + ONE loader wave.
+// Wave-specialised form of igemm_halo_kernel: NW compute waves + loader waves (two since round 6: one for the weight tiles, one for
+// the patch pieces and affine tables; launched with one - UR_HALO_LD1 - the single loader does both, the rounds-3-5 structure).
 // Phase timers in the kernel above (profiles/r3_halo_phase_timers.txt) show where the matrix pipe idles: a CU's DMA path takes
 // ~25 cycles per 1-KiB piece and a wave sits in its buffer_load until the queue accepts it, so with every wave issuing its
 // share at the top of a tap the first MFMA starts 400-660 cycles late (of ~2100), whatever the order or the instruction count.
@@ -1784,7 +1785,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_kernel(const ConvK p) 
 // previous tap's pieces and takes part in the two barriers, which publish them.  It always issues the same number of pieces per
 // tap position (tile / chunk indices clamped at the end: a re-fetch into a slot nobody reads), so its counts are immediates.
 template <int TH, int BN, int WM, int WN, bool F16, bool GNP>
-__global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const ConvK p) {
+__global__ __launch_bounds__((WM * WN + 2) * 64) void igemm_halo_ws_kernel(const ConvK p) {
   constexpr int NW = WM * WN, TW = 32, BM = TH * TW, PW = TW + 2, HPIX = (TH + 2) * PW;
   constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW), HNEED = (HPIX + 7) / 8;          // (LDS layout of the plain kernel); pieces actually read
   constexpr int HPIECES = HSLOTS * NW, HBYTES = HPIECES * 1024;
@@ -1832,8 +1833,14 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const
     return v ? (img * p.H + iy) * p.W + ix : -1;
   };
 
-  if (wid_s == NW) {
-    // ================================================= loader wave ==================================================
+  if (wid_s >= NW) {
+    // ================================================= loader wave(s) ================================================
+    // One loader wave (576-thread launch) issues the weight tiles AND the patch pieces; with a second one (640-thread launch, round 6)
+    // wave NW issues the weight tiles and wave NW + 1 the patch pieces (+ the affine tables): a lone loader is issue-bound on the taps
+    // that carry patch pieces (16-20 weight pieces at ~38 cycles + 6 patch pieces at ~85 against 1 280 MFMA cycles), two waves feed the
+    // CU's DMA path in parallel.  Each wave waits for its own pieces; both take part in both barriers of every tap.
+    const bool two = blockDim.x > (NW + 1) * 64;
+    const bool do_w = wid_s == NW, do_h = two ? wid_s == NW + 1 : true;
     // piece q = LDS rows 8q .. 8q+7; the lane's physical 16-byte slot ps holds logical K chunk ps ^ ((row >> 1) & 7): two parities
     const unsigned ck0 = (ps ^ ((lr >> 1) & 7)) * 16u, ck1 = (ps ^ ((4 + (lr >> 1)) & 7)) * 16u;
     const ig_u32x4 rs_w = ig_make_rsrc(p.w, (unsigned long long)p.Cout * p.ldw * 2);
@@ -1884,11 +1891,16 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const
     // Prologue: the compute waves fetch patch 0 and weight tile 0 themselves (nine waves feed the DMA path 2-3x faster than one, and
     // they have nothing else to do yet); the loader issues the affine table and weight tile 1 - which its own tap-0 wait covers - and
     // builds its pixel table while those fly.
-    if (gnp) dma_ab(0);
-    dma_w(1, 1, 0, WPIECES);
+    if (gnp && do_h) dma_ab(0);
+    if (do_w) dma_w(1, 1, 0, WPIECES);
+    if (do_h) {
 #pragma unroll
-    for (int q = 0; q < HNEED; ++q) hpx[q] = halo_pixel(q * 8 + lr);
-    if (gnp) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPIECES) : "memory");      // the table is in (tile 1 may still fly)
+      for (int q = 0; q < HNEED; ++q) hpx[q] = halo_pixel(q * 8 + lr);
+    }
+    if (gnp && do_h) {                                                             // the table is in (tile 1 may still fly)
+      if (do_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (gnp) __builtin_amdgcn_s_barrier();                              // (the compute waves normalise patch 0 in between)
     for (int c = 0; c < nchunk; ++c) {
@@ -1896,17 +1908,24 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void igemm_halo_ws_kernel(const
       for (int tap = 0; tap < 9; ++tap) {
         const int kt = c * 9 + tap;
         LD_TS(0);
-        dma_w(kt + 2, (tap + 2) % 3, 0, WH);
-        dma_h(c + 1, 2 * tap);
-        if (gnp && tap == 0) dma_ab(c + 1);
+        if (do_w) dma_w(kt + 2, (tap + 2) % 3, 0, WH);
+        if (do_h) {
+          dma_h(c + 1, 2 * tap);
+          if (gnp && tap == 0) dma_ab(c + 1);
+        }
         LD_TS(1);
-        // everything issued in EARLIER taps has landed once only this tap's first half may still be in flight
+        // everything this wave issued in EARLIER taps has landed once only this tap's first half may still be in flight
         if (kt + 1 == nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // last tap: nothing may land behind the barrier (the epilogue reuses LDS)
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WH + halo_count(2 * tap) + ((gnp && tap == 0) ? 1 : 0)) : "memory");
+        else if (do_w && do_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WH + halo_count(2 * tap) + ((gnp && tap == 0) ? 1 : 0)) : "memory");
+        else if (do_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WH) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(halo_count(2 * tap) + ((gnp && tap == 0) ? 1 : 0)) : "memory");
         LD_TS(2);
         __builtin_amdgcn_s_barrier();
         LD_TS(3);
-        if (kt + 1 < nk) { dma_w(kt + 2, (tap + 2) % 3, WH, WPIECES); dma_h(c + 1, 2 * tap + 1); }
+        if (kt + 1 < nk) {
+          if (do_w) dma_w(kt + 2, (tap + 2) % 3, WH, WPIECES);
+          if (do_h) dma_h(c + 1, 2 * tap + 1);
+        }
         LD_TS(4);
         __builtin_amdgcn_s_barrier();
       }
@@ -2119,8 +2138,10 @@ int launch_halo(ConvK& k, hipStream_t s) {
     if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
     else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3(NW * 64), lds, s, k));
   } else {
-    if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_ws_kernel<TH, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3((NW + 1) * 64), lds, s, k));
-    else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_ws_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), dim3((NW + 1) * 64), lds, s, k));
+    static const bool ld1 = getenv("UR_HALO_LD1") != nullptr;             // A/B: one loader wave for weights AND patch pieces (rounds 3-5)
+    const dim3 blk((NW + (ld1 ? 1 : 2)) * 64);
+    if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_ws_kernel<TH, BN, WM, WN, F16, GN_OK>), dim3(k.tiles_m * k.tiles_n, k.splitk), blk, lds, s, k));
+    else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_ws_kernel<TH, BN, WM, WN, F16, false>), dim3(k.tiles_m * k.tiles_n, k.splitk), blk, lds, s, k));
   }
   if (k.splitk > 1) {
     k.patch_tw = 0;                                        // the partial planes are plain [M][Cout]
@@ -2350,6 +2371,177 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_halo_img_kernel(const ConvK
   igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised form of igemm_halo_img_kernel (round 6): 8 compute waves that execute no memory instruction inside the K loop +
+// 2 loader waves - one issues the weight tile two taps ahead, the other the next chunk's halo pieces (spread over taps 0 .. 7) - the
+// structure of igemm_halo_ws_kernel on the whole-image tile.  (With ONE loader wave the kernel was 6 % SLOWER than the self-loading one:
+// 16 weight pieces at ~38 cycles + 8 patch pieces at ~85 exceed the 1 024 MFMA cycles of a tap; two waves feed the CU's DMA path in
+// parallel: 71.2 -> 66.3 us in-graph at 1280 -> 1280 @16x16.)  Same LDS plan, same ring discipline (slot
+// (tap + 2) % 3 was read in the previous tap: every compute wave passed that tap's barrier behind its own lgkmcnt(0)), same
+// accumulation order and epilogue: results are bit-identical to the self-loading kernel.  No fused GroupNorm prologue here (the launches
+// that use it stay on the self-loading kernel).  The prologue fetch (chunk 0's patch, weight tiles 0 and 1) is issued by nine of the ten waves.
+template <int TH, int TW, int NIMG, int BN, int WM, int WN, bool F16>
+__global__ __launch_bounds__((WM * WN + 2) * 64) void igemm_halo_img_ws_kernel(const ConvK p) {
+  constexpr int NW = WM * WN, BM = TH * TW * NIMG, PW = TW + 2, HP = (TH + 2) * PW, HPIX = HP * NIMG;
+  constexpr int HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
+  constexpr int HPIECES = HSLOTS * NW, HBYTES = HPIECES * 1024;
+  constexpr int WBYTES = BN * 128, WPIECES = BN / 8;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32, NT = NW * 64;
+  static_assert(BM == 256 && NW == 8 && WTM % 32 == 0 && WTN % 32 == 0 && HSLOTS <= 8 && ktile_asm_ok<FM, FN>() && WPIECES % NW == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const hbuf = smem;
+  unsigned char* const wring = smem + 2 * HBYTES;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  int sz = blockIdx.y, tn, tmi;
+  if (p.wmajor) {                                            // (see igemm_halo_img_kernel)
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int g = (j / p.tiles_m) * 8 + xcd;
+    if (g >= p.tiles_n * p.splitk) return;
+    tn = g % p.tiles_n; sz = g / p.tiles_n; tmi = j % p.tiles_m;
+  } else {
+    int id = blockIdx.x;
+    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = id & 7, idx = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tn = id % p.tiles_n; tmi = id / p.tiles_n;
+  }
+  const int n0 = tn * BN, img0 = tmi * NIMG, m0 = tmi * BM;
+  const int lr = lane >> 3, ps = lane & 7;
+  const int nchunk_all = p.nk / 9, cps = p.nk_per_split / 9;
+  const int c_begin = sz * cps, c_end = min(nchunk_all, c_begin + cps);
+  const int nchunk = c_end - c_begin, nk = nchunk * 9, kt0 = c_begin * 9;
+  const ig_u32x4 rs_w = ig_make_rsrc(p.w, (unsigned long long)p.Cout * p.ldw * 2);
+  const ig_u32x4 rs_x1 = ig_make_rsrc(p.x, (unsigned long long)p.N * p.H * p.W * p.ldx * 2);
+  const ig_u32x4 rs_x2 = ig_make_rsrc(p.x2 ? p.x2 : p.x, (unsigned long long)p.N * p.H * p.W * (p.x2 ? p.ldx2 : p.ldx) * 2);
+  const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring, hbuf_lds = (unsigned)(uintptr_t)(lptr_t)hbuf;
+
+  // halo piece q (LDS rows 8q .. 8q+7 of the patch): this lane's source pixel (or -1: zero border / surplus row) and its logical 16-byte chunk
+  auto piece_of = [&](int q, int& pix, int& chk) {
+    const int hr = q * 8 + lr;
+    const int im = hr / HP, rin = hr - im * HP, hy = rin / PW, hx = rin - hy * PW;
+    const int iy = hy - 1, ix = hx - 1;
+    const bool v = hr < HPIX && img0 + im < p.N && (unsigned)iy < (unsigned)TH && (unsigned)ix < (unsigned)TW;
+    const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
+    pix = v ? ((img0 + im) * p.H + sy) * p.W + sx : -1;
+    chk = ps ^ (((rin >> 1) - hy) & 7);
+  };
+  auto dma_piece = [&](int c, int q, int pix, int chk) {          // piece q of chunk c (local to this split) -> halo buffer c & 1
+    const int cb = (c_begin + c) * 64;
+    const bool second = cb >= p.C1;
+    const unsigned ld2 = (unsigned)(second ? p.ldx2 : p.ldx) * 2u;
+    const unsigned vo = pix >= 0 ? (unsigned)pix * ld2 + chk * 16u : IG_OOB;
+    const unsigned m0v = hbuf_lds + (c & 1) * HBYTES + q * 1024;
+    if (second) ig_lds_dma16(m0v, vo, rs_x2, (unsigned)(cb - p.C1) * 2u);
+    else ig_lds_dma16(m0v, vo, rs_x1, (unsigned)cb * 2u);
+  };
+  auto wvo_of = [&](int q) -> unsigned {                           // weight piece q (tile rows 8q .. 8q+7): the (row>>1)&7 swizzle on the source
+    const int row = n0 + q * 8 + lr;
+    const int wchunk = ps ^ ((((q & 1) << 2) + (lr >> 1)) & 7);
+    return row < p.Cout ? (unsigned)row * (unsigned)p.ldw * 2u + wchunk * 16u : IG_OOB;
+  };
+
+  if (wid_s == NW) {
+    // ============================================ loader wave 1: the weight tiles ============================================
+    unsigned wvo[WPIECES];
+#pragma unroll
+    for (int q = 0; q < WPIECES; ++q) wvo[q] = wvo_of(q);
+    auto dma_w = [&](int kt, int ring) {
+      const unsigned so = (unsigned)(kt0 + kt) * 128u;
+#pragma unroll
+      for (int q = 0; q < WPIECES; ++q) ig_lds_dma16(wring_lds + ring * WBYTES + q * 1024, wvo[q], rs_w, so);
+    };
+    if (nk > 1) dma_w(1, 1);                                       // prologue share: weight tile 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      // (9 % 3 == 0: the ring slot of tile kt is kt % 3 = tap % 3)
+      if (kt + 2 < nk) {
+        dma_w(kt + 2, (kt + 2) % 3);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPIECES) : "memory");      // everything issued in earlier taps has landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+  if (wid_s == NW + 1) {
+    // ====================================== loader wave 2: the next chunk's halo pieces ======================================
+    int hpx[HPIECES];                                              // pix * 8 + chk (pix = -1 -> negative)
+#pragma unroll
+    for (int q = 0; q < HPIECES; ++q) { int pix, chk; piece_of(q, pix, chk); hpx[q] = pix >= 0 ? pix * 8 + chk : -1; }
+    __builtin_amdgcn_s_barrier();
+    constexpr int PPT = (HPIECES + 7) / 8;                         // pieces per tap over taps 0 .. 7 (tap 8 issues none: all landed before the chunk ends)
+    for (int c = 0; c < nchunk; ++c) {
+      const bool next_chunk = c + 1 < nchunk;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (next_chunk && tap < 8) {
+#pragma unroll
+          for (int j = 0; j < PPT; ++j) {
+            const int q = tap * PPT + j;
+            if (q < HPIECES) dma_piece(c + 1, q, hpx[q < HPIECES ? q : 0] >= 0 ? hpx[q < HPIECES ? q : 0] >> 3 : -1, hpx[q < HPIECES ? q : 0] & 7);
+          }
+        }
+        if (tap == 8 || !next_chunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    return;
+  }
+
+  // =================================================== compute waves ==================================================
+  const int wm = wid % WM, wn = wid / WM;
+  {
+    // prologue fetch: patch of chunk 0 (pieces t * NW + wid) and weight tile 0 (pieces wid, wid + NW, ..)
+#pragma unroll
+    for (int t = 0; t < HSLOTS; ++t) { int pix, chk; piece_of(t * NW + wid_s, pix, chk); dma_piece(0, t * NW + wid_s, pix, chk); }
+#pragma unroll
+    for (int i = 0; i < WPIECES / NW; ++i) ig_lds_dma16(wring_lds + (wid_s + NW * i) * 1024, wvo_of(wid_s + NW * i), rs_w, (unsigned)kt0 * 128u);
+  }
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int hrow0[FM], hin0[FM], hy0[FM];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int pix = wm * WTM + b * 32 + frow;
+    const int im = pix / (TH * TW), r = pix - im * (TH * TW), y = r / TW, x = r - y * TW;
+    hin0[b] = y * PW + x;
+    hrow0[b] = im * HP + hin0[b];
+    hy0[b] = y;
+  }
+  const unsigned aw_lds = wring_lds + (wn * WTN + frow) * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4);
+  static_assert(((WTN >> 1) & 7) == 0, "the wave's weight rows must keep the swizzle phase of fragment row 0");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      unsigned ab[FM];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        const int hsw = (((hin0[b] + dy * PW + dx) >> 1) - (hy0[b] + dy)) & 7;
+        ab[b] = hbuf_lds + (c & 1) * HBYTES + (hrow0[b] + dy * PW + dx) * 128 + ((fhalf ^ hsw) << 4);
+      }
+      ktile_mma<FM, FN, F16>(acc, ab, aw_lds + (tap % 3) * WBYTES);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's fragment reads of the slot / buffer the loader overwrites next are retired
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // last MFMA of the asm tap body -> VALU reads of the accumulators
+  igemm_epilogue<FM, FN, WTM, WTN, BM, BN, NT, F16, false>(p, acc, m0, n0, wm, wn, lane, 0, sz, smem);
+}
+
 template <int TH, int TW, int NIMG, int BN, int WM, int WN>
 int launch_halo_img(ConvK& k, hipStream_t s) {
   constexpr int NW = WM * WN, BM = TH * TW * NIMG, HPIX = (TH + 2) * (TW + 2) * NIMG, HSLOTS = (HPIX + 8 * NW - 1) / (8 * NW);
@@ -2383,7 +2575,13 @@ int launch_halo_img(ConvK& k, hipStream_t s) {
   const int slices = k.tiles_n * k.splitk, per_xcd = ((slices + 7) / 8) * k.tiles_m;
   k.wmajor = !no_wmajor && (long long)k.Cout * k.Ktot > (long long)k.N * k.H * k.W * k.Cin && per_xcd <= 32 && slices >= 8;
   const dim3 grid = k.wmajor ? dim3(8 * per_xcd, 1) : dim3(k.tiles_m * k.tiles_n, k.splitk);
-  if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, GN_OK>), grid, dim3(NW * 64), lds, s, k));
+  static const bool himg_ws = getenv("UR_HIMG_NOWS") == nullptr;        // wave-specialised form (8 compute + 2 loader waves); A/B: every wave loads for itself
+  if (himg_ws && !k.gn_ab) {
+    static ur::DeviceOnce ws_once;
+    if (auto g2 = ws_once.first())
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_img_ws_kernel<TH, TW, NIMG, BN, WM, WN, UR_TU_F16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_ws_kernel<TH, TW, NIMG, BN, WM, WN, F16>), grid, dim3((NW + 2) * 64), lds, s, k));
+  } else if (GN_OK && k.gn_ab) UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, GN_OK>), grid, dim3(NW * 64), lds, s, k));
   else UR_F16_SWITCH(k, hipLaunchKernelGGL((igemm_halo_img_kernel<TH, TW, NIMG, BN, WM, WN, F16, false>), grid, dim3(NW * 64), lds, s, k));
   if (k.splitk > 1) launch_splitk_reduce(k, s);
   return ur::check_launch("ur_conv2d_nhwc");
