@@ -288,7 +288,7 @@ def main():
         sec = dom["ms"] / 1e3
         ach = (dom["flops"] / sec / 1e12) if mf else (dom["bytes"] / sec / 1e9)
         peak = MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBS
-        names = {"conv3x3_igemm": "conv3x3 implicit GEMM (igemm_halo_ws_kernel / igemm_halo_img_kernel + fallbacks)",
+        names = {"conv3x3_igemm": "conv3x3 implicit GEMM (igemm_halo_ws_kernel / igemm_halo_img_ws_kernel / conv3x3_wstream8_kernel + fallbacks)",
                  "gemm1x1_igemm": "1x1 conv / Linear GEMMs (gemm_glds_kernel / igemm_kernel)", "attention": "flash attention (attn_fwd_kernel)",
                  "chain_tail": "token-stationary transformer TAIL chain (tchain_tail_kernel)"}
         result["roofline"] = {"kernel": names.get(dom_name, dom_name) + ", all launches of one forward (the family with the most time)",
