@@ -300,7 +300,9 @@ def main():
                               "share_of_forward": round(dom["ms"] / sum(v["ms"] for v in rep.values()), 3)}
         # HBM bytes of the most frequent launch of the conv family (conv3x3 320->320 @64x64, B=8), from separate rocprofv3 --pmc
         # passes (FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE), committed file; null for other families
-        r6 = os.path.join(ROOT, "profiles", "r6_pmc_conv.json")
+        r6 = os.path.join(ROOT, "profiles", "r6_pmc_conv_final.json")          # the round's final tree (r6_pmc_conv.json: its first pass)
+        if not os.path.exists(r6):
+            r6 = os.path.join(ROOT, "profiles", "r6_pmc_conv.json")
         if dom_name == "conv3x3_igemm" and os.path.exists(r6):
             pj = json.load(open(r6))
             cl = {c["class"]: c for c in pj["classes"]}
@@ -309,7 +311,7 @@ def main():
             result["roofline"]["traffic"] = c0["hbm_bytes_per_launch"]
             result["roofline"]["traffic_algorithmic"] = c0["algorithmic_read_bytes"] + c0["algorithmic_write_bytes"]
             result["roofline"]["traffic_note"] = (
-                "most frequent conv3x3 launch (320->320 @64x64, B=8: 140 per forward), re-measured this round (profiles/r6_pmc_conv.json, separate "
+                "most frequent conv3x3 launch (320->320 @64x64, B=8: 140 per forward), re-measured on this round's final tree (profiles/" + os.path.basename(r6) + ", separate "
                 f"--pmc passes, FETCH_SIZE x2 gfx950 wide-read correction + WRITE_SIZE): {c0['hbm_over_algorithmic']} x algorithmic (halo rows re-read by "
                 f"neighbouring 8x32 patches); matrix pipe busy {k0['mfma_busy_frac']:.3f} of the launch's GPU cycles.  HBM-side bytes / algorithmic per "
                 "conv class (same file): " + ", ".join(f"{c['class']} {c['hbm_over_algorithmic']}" for c in pj["classes"]) +

@@ -24,7 +24,9 @@ CLASSES = {
 
 
 def main():
-    raw = open(os.path.join(ROOT, "profiles", "r6_pmc_conv_raw.txt")).read().split("== wstream timeline")[0]
+    src = sys.argv[1] if len(sys.argv) > 1 else "r6_pmc_conv_raw.txt"          # (r6_pmc_conv_final_raw.txt: the final tree of the round)
+    final = "final" in src
+    raw = open(os.path.join(ROOT, "profiles", src)).read().split("== wstream timeline")[0]
     data = {}
     cls = None
     for line in raw.splitlines():
@@ -37,10 +39,12 @@ def main():
             kern = re.sub(r"\(\(?ano.*$", "", m.group(1)).strip() or "splitk_reduce*_kernel"
             if kern.startswith("ConvK)"):
                 kern = "splitk_reduce_gn_kernel (name cut by the 70-character key)"
+            elif kern == "ConvK":
+                kern = "conv3x3_wstream8_kernel (name cut by the 90-character key)"
             d = data.setdefault(cls, {}).setdefault((kern, int(m.group(2)), int(m.group(3))), {})
             d.update(ast.literal_eval(m.group(4)))
     out = {"round": 6,
-           "source": "profiles/r6_pmc_conv_raw.txt (tools/r6/probe1.sh / probe2.sh: separate rocprofv3 --kernel-trace --pmc passes per counter group, per-launch "
+           "source": f"profiles/{src} (tools/r6/probe1.sh / probe2.sh, final tree: tools/r6/pmc_conv_final.sh: separate rocprofv3 --kernel-trace --pmc passes per counter group, per-launch "
                      "averages over 18 launches of tools/r6/time_conv.py-style loops; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md)",
            "normalisation": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (128 x GRBM_GUI_ACTIVE) [GRBM summed over 8 XCDs, MFMA_BUSY over 1024 SIMDs]; "
                             "wave-cycle split in quad-cycles over SQ_WAVE_CYCLES; lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE",
@@ -72,14 +76,17 @@ def main():
             entry["kernels"].append(k)
         # class-level traffic: sum over the kernels of one launch sequence (conv + its reduce pass); the generic-kernel A/B twin that
         # some passes also recorded for the 16x16 class is left out of the sum
-        main_k = [k for k in entry["kernels"] if "hbm_side_fetch_bytes" in k and not (cls == "unet c3 1280->1280@16" and k["kernel"].startswith("igemm_kernel"))]
+        main_k = [k for k in entry["kernels"] if "hbm_side_fetch_bytes" in k and not (not final and cls == "unet c3 1280->1280@16" and k["kernel"].startswith("igemm_kernel"))]
         # the 16x16 class recorded two reduce launches per conv (one per variant): halve
-        f = sum(k["hbm_side_fetch_bytes"] * (0.5 if cls == "unet c3 1280->1280@16" and "reduce" in k["kernel"] else 1) for k in main_k)
-        wr = sum(k["hbm_side_write_bytes"] * (0.5 if cls == "unet c3 1280->1280@16" and "reduce" in k["kernel"] else 1) for k in main_k)
+        f = sum(k["hbm_side_fetch_bytes"] * (0.5 if not final and cls == "unet c3 1280->1280@16" and "reduce" in k["kernel"] else 1) for k in main_k)
+        wr = sum(k["hbm_side_write_bytes"] * (0.5 if not final and cls == "unet c3 1280->1280@16" and "reduce" in k["kernel"] else 1) for k in main_k)
         entry["hbm_bytes_per_launch"] = int(f + wr)
         entry["hbm_over_algorithmic"] = round((f + wr) / (alg_r + alg_w), 2)
         out["classes"].append(entry)
-    dst = os.path.join(ROOT, "profiles", "r6_pmc_conv.json")
+    if final:
+        out["note"] = ("final tree of round 6: two loader waves in the 8 x 32 halo conv, the wave-specialised whole-image kernel with the weight-major XCD map, the "
+                       "8 x 8 weight stream; the '@16' class averages the plain and the fused-upsample launch (the shape filter matches both)")
+    dst = os.path.join(ROOT, "profiles", "r6_pmc_conv_final.json" if final else "r6_pmc_conv.json")
     json.dump(out, open(dst, "w"), indent=1)
     for e in out["classes"]:
         ks = e["kernels"][0]
